@@ -1,0 +1,20 @@
+"""accbpg_and_fw_amd -- MI355X-native implementation of the D-optimal-design hot path of
+accbpg (DredderGun/accbpg_and_fw): BPG / ABPG / ABPG_gain with the Burg-entropy simplex
+kernel, and D_opt_FW / D_opt_FW_away, behind the reference's own names and signatures.
+
+    import accbpg_and_fw_amd as accbpg
+    f, h, L, x0 = accbpg.D_opt_design(80, 200)
+    x, F, G, T = accbpg.BPG(f, h, L, x0, maxitrs=1000)
+
+All arithmetic runs in hand-written gfx950 HIP kernels (accbpg_and_fw_amd/csrc) through a
+ctypes C-ABI (include/accbpg_hip.h); there is no CPU fallback.
+"""
+from .functions import (RSmoothFunction, DOptimalObj, LegendreFunction, BurgEntropy,
+                        BurgEntropySimplex)
+from .algorithms import BPG, ABPG, ABPG_gain, solve_theta
+from .D_opt_alg import D_opt_FW, D_opt_FW_away
+from .applications import D_opt_design
+
+__all__ = ["RSmoothFunction", "DOptimalObj", "LegendreFunction", "BurgEntropy", "BurgEntropySimplex",
+           "BPG", "ABPG", "ABPG_gain", "solve_theta", "D_opt_FW", "D_opt_FW_away", "D_opt_design"]
+__version__ = "0.1.0"

@@ -1,0 +1,266 @@
+"""Outer loops of BPG / ABPG / ABPG_gain with the reference's signatures, defaults,
+return tuples, print tables and quirks (accbpg/algorithms.py:11-180, 295-420), running
+on device vectors.  The host keeps the iteration and every scalar decision; all
+length-n and matrix work goes through libaccbpg_hip.so via the f / h objects of
+``functions.py`` and the fused vector helpers there.
+
+``x0`` may be a NumPy array (results come back as NumPy) or an fp64 CUDA tensor
+(results stay on the device).  ``T[k]`` is stamped after ``F[k]`` has been read back
+from the GPU, as the reference stamps it after ``F[k]`` is computed.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from .functions import BurgEntropy, from_dev, ls_terms, to_dev, vec_axpby, vec_dot_diff
+
+
+def _divergences(h, g, x, y, z, z_prev):
+    """(<g, x-y>, D(x,y), D(z,z_prev)); one fused launch when h is this package's Burg kernel."""
+    if isinstance(h, BurgEntropy):
+        return ls_terms(g, x, y, z, z_prev)
+    return vec_dot_diff(g, x, y), h.divergence(x, y), h.divergence(z, z_prev)
+
+
+def _drain(gen):
+    """Run a step generator to completion and return its result."""
+    while True:
+        try:
+            next(gen)
+        except StopIteration as stop:
+            return stop.value
+
+
+def BPG(f, h, L, x0, maxitrs, epsilon=1e-14, linesearch=True, ls_ratio=1.2,
+        verbose=True, verbskip=1):
+    """Bregman proximal gradient method (accbpg/algorithms.py:11-72).
+
+    Returns (x, F, Ls, T).  F[k] is the objective at the iterate *before* update k
+    (:47), so the returned x is one step past F[-1]; L is carried between iterations
+    and divided by ls_ratio before each backtracking search (:51)."""
+    return _drain(BPG_steps(f, h, L, x0, maxitrs, epsilon, linesearch, ls_ratio, verbose, verbskip))
+
+
+def BPG_steps(f, h, L, x0, maxitrs, epsilon=1e-14, linesearch=True, ls_ratio=1.2,
+              verbose=True, verbskip=1):
+    """Generator form of BPG: yields k after each outer iteration, returns BPG's tuple."""
+    if verbose:
+        print("\nBPG_LS method for min_{x in C} F(x) = f(x) + Psi(x)")
+        print("     k      F(x)         Lk       time")
+
+    t_start = time.time()
+    F = np.zeros(maxitrs)
+    Ls = np.ones(maxitrs) * L
+    T = np.zeros(maxitrs)
+
+    x, as_numpy = to_dev(x0)
+    x = x.clone()
+    k = -1
+    for k in range(maxitrs):
+        fx, g = f.func_grad(x)
+        F[k] = fx + h.extra_Psi(x)
+        T[k] = time.time() - t_start
+
+        if linesearch:
+            L = L / ls_ratio
+            trial = h.div_prox_map(x, g, L)
+            while True:
+                lin, dist, _ = _divergences(h, g, trial, x, None, None)
+                if not (f(trial) > fx + lin + L * dist):        # algorithms.py:53
+                    break
+                L = L * ls_ratio
+                trial = h.div_prox_map(x, g, L)
+            x = trial
+        else:
+            x = h.div_prox_map(x, g, L)
+
+        Ls[k] = L
+        if verbose and k % verbskip == 0:
+            print("{0:6d}  {1:10.3e}  {2:10.3e}  {3:6.1f}".format(k, F[k], L, T[k]))
+
+        if k > 0 and abs(F[k] - F[k - 1]) < epsilon:            # algorithms.py:66
+            break
+        yield k
+
+    return from_dev(x, as_numpy), F[0:k + 1], Ls[0:k + 1], T[0:k + 1]
+
+
+def solve_theta(theta, gamma, gainratio=1):
+    """Newton solve of (1-t)/t^gamma = gainratio/theta^gamma from t = theta, tolerance
+    1e-6*theta (accbpg/algorithms.py:75-91).  Pure host scalar arithmetic."""
+    ckg = theta ** gamma / gainratio
+    cta = theta
+    eps = 1e-6 * theta
+    phi = cta ** gamma - ckg * (1 - cta)
+    while abs(phi) > eps:
+        drv = gamma * cta ** (gamma - 1) + ckg
+        cta = cta - phi / drv
+        phi = cta ** gamma - ckg * (1 - cta)
+    return cta
+
+
+def ABPG(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=False,
+         restart=False, restart_rule='g', verbose=True, verbskip=1):
+    """Accelerated BPG with fixed triangle-scaling exponent (accbpg/algorithms.py:94-180).
+    Returns (x, F, G, T)."""
+    return _drain(ABPG_steps(f, h, L, x0, gamma, maxitrs, epsilon, theta_eq, restart, restart_rule,
+                             verbose, verbskip))
+
+
+def ABPG_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=False,
+               restart=False, restart_rule='g', verbose=True, verbskip=1):
+    """Generator form of ABPG: yields k after each outer iteration, returns ABPG's tuple."""
+    if verbose:
+        print("\nABPG method for minimize_{x in C} F(x) = f(x) + Psi(x)")
+        print("     k      F(x)       theta" +
+              "        TSG       D(x+,y)     D(z+,z)     time")
+
+    t_start = time.time()
+    F = np.zeros(maxitrs)
+    G = np.zeros(maxitrs)
+    T = np.zeros(maxitrs)
+
+    x, as_numpy = to_dev(x0)
+    x = x.clone()
+    z = x.clone()
+    theta = 1.0
+    kk = 0
+    k = -1
+    for k in range(maxitrs):
+        F[k] = f(x) + h.extra_Psi(x)                            # :135-136
+        T[k] = time.time() - t_start
+
+        z_prev, x_prev = z, x
+        if theta_eq and kk > 0:                                 # :142-145
+            theta = solve_theta(theta, gamma)
+        else:
+            theta = gamma / (kk + gamma)
+
+        y = vec_axpby(1 - theta, x, theta, z_prev)              # :147
+        g = f.gradient(y)                                       # :148
+        z = h.div_prox_map(z_prev, g, theta ** (gamma - 1) * L)  # :149
+        x = vec_axpby(1 - theta, x, theta, z)                   # :150
+
+        _, dxy, dzz = _divergences(h, None, x, y, z, z_prev)    # :153-154
+        Gdr = dxy / dzz / theta ** gamma                        # :155
+
+        G[k] = Gdr
+        if verbose and k % verbskip == 0:
+            print("{0:6d}  {1:10.3e}  {2:10.3e}  {3:10.3e}  {4:10.3e}  {5:10.3e}  {6:6.1f}".format(
+                k, F[k], theta, Gdr, dxy, dzz, T[k]))
+
+        kk += 1
+        if restart and k > 0:                                   # :165-171
+            if (restart_rule == 'f' and F[k] > F[k - 1]) or \
+               (restart_rule == 'g' and vec_dot_diff(g, x, x_prev) > 0):
+                theta = 1.0
+                kk = 0
+                z = x
+
+        if dzz < epsilon:                                       # :174
+            break
+        yield k
+
+    return from_dev(x, as_numpy), F[0:k + 1], G[0:k + 1], T[0:k + 1]
+
+
+def ABPG_gain(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, G0=1,
+              ls_inc=1.2, ls_dec=1.2, theta_eq=True, checkdiv=False,
+              restart=False, restart_rule='g', verbose=True, verbskip=1):
+    """Accelerated BPG with gain adaption (accbpg/algorithms.py:295-420).
+    Returns (x, F, Gain, Gdiv, Gavg, T).
+
+    Quirks kept: the gain is cut by ls_dec before every search (:358); an inner break
+    on D(z+,z) < epsilon records the previous Gdr (:379-382, NameError in the reference
+    if that happens at k = 0 -- here it records 0.0); the restart test has no k > 0
+    guard, so rule 'f' at k = 0 compares with F[-1] (:403-406)."""
+    return _drain(ABPG_gain_steps(f, h, L, x0, gamma, maxitrs, epsilon, G0, ls_inc, ls_dec, theta_eq,
+                                  checkdiv, restart, restart_rule, verbose, verbskip))
+
+
+def ABPG_gain_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, G0=1,
+                    ls_inc=1.2, ls_dec=1.2, theta_eq=True, checkdiv=False,
+                    restart=False, restart_rule='g', verbose=True, verbskip=1):
+    """Generator form of ABPG_gain: yields k after each outer iteration, returns its tuple."""
+    if verbose:
+        print("\nABPG_gain method for min_{x in C} F(x) = f(x) + Psi(x)")
+        print("     k      F(x)       theta         Gk" +
+              "         TSG       D(x+,y)     D(z+,z)      Gavg       time")
+
+    t_start = time.time()
+    F = np.zeros(maxitrs)
+    Gain = np.ones(maxitrs) * G0
+    Gdiv = np.zeros(maxitrs)
+    Gavg = np.zeros(maxitrs)
+    T = np.zeros(maxitrs)
+
+    x, as_numpy = to_dev(x0)
+    x = x.clone()
+    z = x.clone()
+    G = G0
+    sumlogG = gamma * np.log(G)                                 # :342
+    theta = 1.0
+    kk = 0
+    Gdr = 0.0
+    k = -1
+    for k in range(maxitrs):
+        F[k] = f(x) + h.extra_Psi(x)                            # :347-348
+        T[k] = time.time() - t_start
+
+        z_prev, x_prev = z, x
+        G_prev, theta_prev = G, theta
+        G = G / ls_dec                                          # :358
+
+        searching = True
+        while searching:                                        # :361
+            if kk > 0:
+                if theta_eq:
+                    theta = solve_theta(theta_prev, gamma, G / G_prev)
+                else:
+                    alpha = G / G_prev
+                    theta = theta_prev * ((1 + alpha * (gamma - 1)) / (gamma * alpha + theta_prev))
+
+            y = vec_axpby(1 - theta, x_prev, theta, z_prev)     # :369
+            fy, g = f.func_grad(y)                              # :371
+            z = h.div_prox_map(z_prev, g, theta ** (gamma - 1) * G * L)   # :373
+            x = vec_axpby(1 - theta, x_prev, theta, z)          # :374
+
+            lin, dxy, dzz = _divergences(h, g, x, y, z, z_prev)  # :377-378 and the dot of :387
+            if dzz < epsilon:                                   # :379-380
+                break
+
+            Gdr = dxy / dzz / theta ** gamma                    # :382
+
+            if checkdiv:
+                searching = (Gdr > G)                           # :385
+            else:
+                searching = (f(x) > fy + lin + theta ** gamma * G * L * dzz)   # :387
+
+            if searching:
+                G = G * ls_inc                                  # :390
+
+        Gain[k] = G
+        Gdiv[k] = Gdr
+        sumlogG += np.log(G)
+        Gavg[k] = np.exp(sumlogG / (gamma + k))                 # :395-396
+        if verbose and k % verbskip == 0:
+            print("{0:6d}  {1:10.3e}  {2:10.3e}  {3:10.3e}  {4:10.3e}  {5:10.3e}  {6:10.3e}  {7:10.3e}  {8:6.1f}".format(
+                k, F[k], theta, G, Gdr, dxy, dzz, Gavg[k], T[k]))
+
+        kk += 1
+        if restart:                                             # :403-409
+            if (restart_rule == 'f' and F[k] > F[k - 1]) or \
+               (restart_rule == 'g' and vec_dot_diff(g, x, x_prev) > 0):
+                theta = 1.0
+                kk = 0
+                z = x
+
+        if dzz < epsilon:                                       # :412
+            break
+        yield k
+
+    return (from_dev(x, as_numpy), F[0:k + 1], Gain[0:k + 1], Gdiv[0:k + 1],
+            Gavg[0:k + 1], T[0:k + 1])

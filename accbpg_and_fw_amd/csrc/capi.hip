@@ -1,0 +1,189 @@
+// C-ABI entry points of libaccbpg_hip.so (see include/accbpg_hip.h for the contract).
+#include <stdarg.h>
+#include <string.h>
+
+#include "internal.h"
+
+namespace accbpg {
+
+static thread_local char g_err[512] = "";
+
+void set_last_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+__global__ void check_nonneg_kernel(const double* __restrict__ x, int64_t n, int* __restrict__ flags) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (!(x[i] >= 0.0)) bad = true;
+    if (bad) flags[FLAG_NEG_X] = 1;
+}
+
+static int read_status(accbpg_dopt* h) {
+    ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+    ACC_HIP(hipMemcpyAsync(h->hpin + 16, h->dflag, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));
+    ACC_HIP(hipStreamSynchronize(h->stream));
+    return ACCBPG_OK;
+}
+
+}  // namespace accbpg
+
+using namespace accbpg;
+
+extern "C" int accbpg_abi_version(void) { return 1; }
+extern "C" const char* accbpg_last_error(void) { return g_err; }
+
+extern "C" int accbpg_dopt_create(const double* V_dev, int64_t m, int64_t n, int64_t ldv, void* stream,
+                                  accbpg_dopt** out) {
+    if (!V_dev || !out || m <= 0 || n <= 0 || ldv < n) {
+        set_last_error("accbpg_dopt_create: bad arguments (m=%lld n=%lld ldv=%lld)", (long long)m, (long long)n,
+                       (long long)ldv);
+        return ACCBPG_ERR_ARG;
+    }
+    if (!(m < n)) {                         // DOptimalObj: need m < n   (functions.py:35)
+        set_last_error("DOptimalObj: need m < n");
+        return ACCBPG_ERR_ASSERT;
+    }
+    accbpg_dopt* h = new accbpg_dopt();
+    h->V = V_dev; h->m = m; h->n = n; h->ldv = ldv; h->stream = (hipStream_t)stream;
+    ACC_HIP(hipGetDevice(&h->device));
+    hipDeviceProp_t prop;
+    ACC_HIP(hipGetDeviceProperties(&prop, h->device));
+    h->num_cu = prop.multiProcessorCount;
+    h->big = (m >= 768);
+    h->vec_ok = ((reinterpret_cast<uintptr_t>(V_dev) & 15) == 0) && ((ldv & 1) == 0);
+    const size_t mm = sizeof(double) * (size_t)m * (size_t)m;
+    ACC_HIP(hipMalloc(&h->Lbuf, mm));
+    ACC_HIP(hipMalloc(&h->Wbuf, mm));
+    ACC_HIP(hipMalloc(&h->Tbuf, mm));
+    ACC_HIP(hipMemset(h->Lbuf, 0, mm));
+    ACC_HIP(hipMemset(h->Wbuf, 0, mm));     // the upper triangle of W must read as zero
+    ACC_HIP(hipMemset(h->Tbuf, 0, mm));
+    ACC_HIP(hipMalloc(&h->dscal, sizeof(double) * 16));
+    ACC_HIP(hipMalloc(&h->dflag, sizeof(int) * 8));
+    ACC_HIP(hipMemset(h->dscal, 0, sizeof(double) * 16));
+    ACC_HIP(hipMemset(h->dflag, 0, sizeof(int) * 8));
+    ACC_HIP(hipHostMalloc(&h->hpin, sizeof(double) * 32, hipHostMallocDefault));
+    const int64_t vws = std::max<int64_t>(vec_ws_doubles(n), 64 * n);
+    ACC_HIP(hipMalloc(&h->vws, sizeof(double) * (size_t)vws));
+    int rc = build_plans(h);
+    if (rc != ACCBPG_OK) { accbpg_dopt_destroy(h); return rc; }
+    *out = h;
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_dopt_destroy(accbpg_dopt* h) {
+    if (!h) return ACCBPG_OK;
+    hipFree(h->Lbuf); hipFree(h->Wbuf); hipFree(h->Tbuf); hipFree(h->slabs); hipFree(h->tiles);
+    hipFree(h->dscal); hipFree(h->dflag); hipFree(h->vws); hipFree(h->ops); hipFree(h->chol_op);
+    hipFree(h->fw_x); hipFree(h->fw_w); hipFree(h->fw_H); hipFree(h->fw_hv);
+    if (h->hpin) hipHostFree(h->hpin);
+    for (auto& p : h->prof)
+        for (auto e : p.ev) hipEventDestroy(e);
+    delete h;
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_dopt_set_stream(accbpg_dopt* h, void* stream) {
+    if (!h) return ACCBPG_ERR_ARG;
+    h->stream = (hipStream_t)stream;
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_dopt_gram(accbpg_dopt* h, const double* x_dev, double* gram_dev) {
+    if (!h || !x_dev || !gram_dev) return ACCBPG_ERR_ARG;
+    return launch_gram(h, x_dev, gram_dev);
+}
+
+extern "C" int accbpg_dopt_factor(accbpg_dopt* h, const double* gram_dev, double* f_host) {
+    if (!h || !gram_dev) return ACCBPG_ERR_ARG;
+    if (gram_dev != h->Lbuf)
+        ACC_HIP(hipMemcpyAsync(h->Lbuf, gram_dev, sizeof(double) * h->m * h->m, hipMemcpyDeviceToDevice, h->stream));
+    ACC_TRY(launch_cholesky(h, h->Lbuf));
+    ACC_TRY(read_status(h));
+    const int* fl = reinterpret_cast<const int*>(h->hpin + 16);
+    if (fl[FLAG_NOT_PD]) {
+        set_last_error("HXHT is singular or not positive definite");
+        return ACCBPG_ERR_NOT_PD;
+    }
+    if (f_host) *f_host = -h->hpin[0];       // f = -logdet   (functions.py:51)
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_dopt_grad(accbpg_dopt* h, double* g_dev) {
+    if (!h || !g_dev) return ACCBPG_ERR_ARG;
+    ACC_TRY(launch_trtri(h));
+    ACC_TRY(launch_colnorm(h, h->Wbuf, g_dev, -1.0));
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_dopt_func_grad(accbpg_dopt* h, const double* x_dev, int flag, double* f_host, double* g_dev) {
+    if (!h || !x_dev || flag < 0 || flag > 2) return ACCBPG_ERR_ARG;
+    if (flag != 0 && !g_dev) return ACCBPG_ERR_ARG;
+    ACC_TRY(launch_gram(h, x_dev, h->Lbuf));
+    ACC_TRY(launch_cholesky(h, h->Lbuf));                       // resets the flags first
+    check_nonneg_kernel<<<64, 256, 0, h->stream>>>(x_dev, h->n, h->dflag);      // functions.py:45
+    if (flag != 0) {
+        // gradient work is queued before the status readback so the host never idles the GPU
+        ACC_TRY(launch_trtri(h));
+        ACC_TRY(launch_colnorm(h, h->Wbuf, g_dev, -1.0));
+    }
+    ACC_TRY(read_status(h));
+    const int* fl = reinterpret_cast<const int*>(h->hpin + 16);
+    if (fl[FLAG_NEG_X]) {
+        set_last_error("DOptimalObj: x needs to be nonnegative");
+        return ACCBPG_ERR_ASSERT;
+    }
+    if (fl[FLAG_NOT_PD]) {
+        set_last_error("HXHT is singular or not positive definite");
+        return ACCBPG_ERR_NOT_PD;
+    }
+    if (f_host) *f_host = -h->hpin[0];
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_dopt_profile_enable(accbpg_dopt* h, int enable) {
+    if (!h) return ACCBPG_ERR_ARG;
+    h->prof_on = enable != 0;
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_dopt_profile_reset(accbpg_dopt* h) {
+    if (!h) return ACCBPG_ERR_ARG;
+    ACC_HIP(hipStreamSynchronize(h->stream));
+    for (auto& p : h->prof) { p.used = 0; p.total_ms = 0.0; p.launches = 0; }
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_dopt_profile_read(accbpg_dopt* h, int which, double* total_ms_host, int64_t* launches_host) {
+    if (!h || which < 0 || which >= PROF_COUNT) return ACCBPG_ERR_ARG;
+    ACC_HIP(hipStreamSynchronize(h->stream));
+    ProfSlot& p = h->prof[which];
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < p.used; i += 2) {
+        float ms = 0.f;
+        ACC_HIP(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
+        tot += ms;
+    }
+    p.total_ms = tot;
+    if (total_ms_host) *total_ms_host = tot;
+    if (launches_host) *launches_host = p.launches;
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_mfma_f64_peak(int iters, double* tflops_host, void* stream) {
+    if (!tflops_host || iters <= 0) return ACCBPG_ERR_ARG;
+    return mfma_peak(iters, tflops_host, (hipStream_t)stream);
+}
+
+extern "C" int accbpg_test_gemm(const double* A_dev, int64_t lda, const double* B_dev, int64_t ldb, double* C_dev,
+                                int64_t ldc, int64_t M, int64_t N, int64_t K, int b_kmajor, double alpha,
+                                double beta, int config, void* stream) {
+    if (!A_dev || !B_dev || !C_dev || M <= 0 || N <= 0 || K <= 0) return ACCBPG_ERR_ARG;
+    return launch_test_gemm(A_dev, lda, B_dev, ldb, C_dev, ldc, M, N, K, b_kmajor, alpha, beta, config,
+                            (hipStream_t)stream);
+}

@@ -1,0 +1,308 @@
+// Frank-Wolfe / Wolfe-Atwood step kernels for D-optimal design on gfx950.
+// Replaces the loop bodies of D_opt_FW and D_opt_FW_away (accbpg/D_opt_alg.py:51-82, 135-179).
+// Every kernel here is HBM- or latency-bound: the step reads V once (8*m*n bytes) for
+// u = Hv^T V, reads and rewrites the m x m inverse H for the rank-one update, and makes a few
+// passes over the length-n vectors.  Compiled with -ffp-contract=off (NumPy ufunc rounding).
+#include "internal.h"
+
+namespace accbpg {
+
+constexpr int FB = 256;
+constexpr int PROBE_T = 1024;
+constexpr int VG_COLS = 2 * FB;      // columns of V per workgroup in the V^T Hv pass
+constexpr int VG_MAXSPLIT = 64;
+
+struct ValIdx {
+    double v;
+    int64_t i;
+};
+
+// first-index-on-ties argmax / argmin, the NumPy convention (D_opt_alg.py:59,61,145,147)
+__device__ __forceinline__ ValIdx better_max(ValIdx a, ValIdx b) {
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ ValIdx better_min(ValIdx a, ValIdx b) {
+    return (b.v < a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ ValIdx shfl_down_vi(ValIdx a, int off) {
+    ValIdx r;
+    r.v = __shfl_down(a.v, off);
+    r.i = __shfl_down((long long)a.i, off);
+    return r;
+}
+
+template <bool IS_MAX>
+__device__ __forceinline__ ValIdx block_reduce_vi(ValIdx a, ValIdx* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ValIdx o = shfl_down_vi(a, off);
+        a = IS_MAX ? better_max(a, o) : better_min(a, o);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = a;
+    __syncthreads();
+    ValIdx r = sh[0];
+    for (int i = 1; i < PROBE_T / 64; ++i) r = IS_MAX ? better_max(r, sh[i]) : better_min(r, sh[i]);
+    return r;
+}
+
+// One workgroup scans w and x: i = argmax w; then the away index.
+//   away == 0: min of w over {x > 0}                               (D_opt_alg.py:60-61)
+//   away == 1: j = argmin (w - w_i) * [x > 1e-8], first index      (D_opt_alg.py:146-147)
+// out: {i, j} as doubles would lose range, so indices go to iout[0..1]; dout = {w_i, w_j, x_j}.
+__global__ __launch_bounds__(PROBE_T) void fw_probe_kernel(const double* __restrict__ w,
+                                                          const double* __restrict__ x, int64_t n, int away,
+                                                          double* __restrict__ dout, int64_t* __restrict__ iout) {
+    __shared__ ValIdx sh[PROBE_T / 64];
+    const double inf = __builtin_inf();
+    ValIdx best{-inf, INT64_MAX};
+    for (int64_t k = threadIdx.x; k < n; k += PROBE_T) best = better_max(best, ValIdx{w[k], k});
+    const ValIdx mx = block_reduce_vi<true>(best, sh);
+    ValIdx lo{inf, INT64_MAX};
+    if (away) {
+        for (int64_t k = threadIdx.x; k < n; k += PROBE_T) {
+            const double ww = w[k] - mx.v;                     // ww = w - w[i]
+            const double mask = (x[k] > 1.0e-8) ? 1.0 : 0.0;
+            lo = better_min(lo, ValIdx{ww * mask, k});         // -0.0 == 0.0 ties resolve by index
+        }
+    } else {
+        for (int64_t k = threadIdx.x; k < n; k += PROBE_T)
+            if (x[k] > 0.0) lo = better_min(lo, ValIdx{w[k], k});
+    }
+    const ValIdx mn = block_reduce_vi<false>(lo, sh);
+    if (threadIdx.x == 0) {
+        iout[0] = mx.i;
+        iout[1] = mn.i;
+        dout[0] = mx.v;
+        const bool ok = mn.i >= 0 && mn.i < n;
+        dout[1] = ok ? w[mn.i] : inf;
+        dout[2] = ok ? x[mn.i] : 0.0;
+    }
+}
+
+// x <- x*xscale; x[p] += xadd   (D_opt_alg.py:76-77,164-165,173-174); vp <- V[:,p]
+__global__ __launch_bounds__(FB) void fw_xupdate_gather_kernel(double* __restrict__ x, int64_t n, int64_t p,
+                                                              double xscale, double xadd,
+                                                              const double* __restrict__ V, int64_t ldv, int64_t m,
+                                                              double* __restrict__ vp) {
+    const int64_t stride = (int64_t)gridDim.x * FB;
+    for (int64_t k = (int64_t)blockIdx.x * FB + threadIdx.x; k < n; k += stride) {
+        double v = x[k] * xscale;
+        if (k == p) v += xadd;
+        x[k] = v;
+    }
+    for (int64_t r = (int64_t)blockIdx.x * FB + threadIdx.x; r < m; r += stride) vp[r] = V[r * ldv + p];
+}
+
+// hv = H vp, one wave per row of H          (np.dot(H, V[:,i]), D_opt_alg.py:78,166,175)
+__global__ __launch_bounds__(FB) void fw_gemv_h_kernel(const double* __restrict__ H, int64_t m,
+                                                      const double* __restrict__ vp, double* __restrict__ hv) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (FB / 64) + (threadIdx.x >> 6);
+    if (row >= m) return;
+    const double* hr = H + row * m;
+    double s = 0.0;
+    for (int64_t c = lane; c < m; c += 64) s = fma(hr[c], vp[c], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (lane == 0) hv[row] = s;
+}
+
+// H <- (H + hcoef*outer(hv,hv)) / hdiv       (D_opt_alg.py:79,167,176)
+__global__ __launch_bounds__(FB) void fw_rank1_kernel(double* __restrict__ H, int64_t m,
+                                                     const double* __restrict__ hv, double hcoef, double hdiv) {
+    const int64_t total = m * m;
+    const int64_t stride = (int64_t)gridDim.x * FB;
+    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / m, c = e - r * m;
+        const double o = hv[r] * hv[c];
+        const double t = hcoef * o;
+        H[e] = (H[e] + t) / hdiv;
+    }
+}
+
+// partial u[s][k] = sum over the rows of split s of hv[r]*V[r][k]; two columns per thread
+__global__ __launch_bounds__(FB) void fw_vgemv_partial_kernel(const double* __restrict__ V, int64_t ldv, int64_t m,
+                                                             int64_t n, const double* __restrict__ hv, int nsplit,
+                                                             double* __restrict__ upart, bool vec_ok) {
+    const int64_t k = (int64_t)blockIdx.x * VG_COLS + 2 * threadIdx.x;
+    const int s = blockIdx.y;
+    const int64_t rows_per = (m + nsplit - 1) / nsplit;
+    const int64_t r0 = (int64_t)s * rows_per, r1 = min(m, r0 + rows_per);
+    if (k >= n) return;
+    double a0 = 0.0, a1 = 0.0;
+    const bool pair = vec_ok && (k + 1 < n);
+    if (pair) {
+        const double* vp = V + r0 * ldv + k;
+#pragma unroll 8
+        for (int64_t r = r0; r < r1; ++r) {
+            const double2 v = *reinterpret_cast<const double2*>(vp);
+            const double h = hv[r];
+            a0 = fma(h, v.x, a0);
+            a1 = fma(h, v.y, a1);
+            vp += ldv;
+        }
+    } else {
+        for (int64_t r = r0; r < r1; ++r) {
+            const double h = hv[r];
+            a0 = fma(h, V[r * ldv + k], a0);
+            if (k + 1 < n) a1 = fma(h, V[r * ldv + k + 1], a1);
+        }
+    }
+    upart[(int64_t)s * n + k] = a0;
+    if (k + 1 < n) upart[(int64_t)s * n + k + 1] = a1;
+}
+
+// w <- (w + hcoef * u^2) / hdiv with u = sum of the partials     (D_opt_alg.py:82,170,179)
+__global__ __launch_bounds__(FB) void fw_wupdate_kernel(double* __restrict__ w, int64_t n,
+                                                       const double* __restrict__ upart, int nsplit, double hcoef,
+                                                       double hdiv) {
+    const int64_t stride = (int64_t)gridDim.x * FB;
+    for (int64_t k = (int64_t)blockIdx.x * FB + threadIdx.x; k < n; k += stride) {
+        double u = 0.0;
+        for (int s = 0; s < nsplit; ++s) u += upart[(int64_t)s * n + k];
+        const double sq = u * u;
+        const double t = hcoef * sq;
+        w[k] = (w[k] + t) / hdiv;
+    }
+}
+
+// out = in^T for an m x m matrix (used once per fw_init to form H = W^T W on the MFMA engine)
+__global__ __launch_bounds__(FB) void transpose_kernel(const double* __restrict__ in, double* __restrict__ out,
+                                                      int64_t m) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+    for (int j = ty; j < 32; j += 8)
+        tile[j][tx] = (r0 + j < m && c0 + tx < m) ? in[(r0 + j) * m + c0 + tx] : 0.0;
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < m && r0 + tx < m) out[(c0 + j) * m + r0 + tx] = tile[tx][j];
+}
+
+// symmetrise: copy the lower triangle of H onto the upper one
+__global__ __launch_bounds__(FB) void mirror_lower_kernel(double* __restrict__ H, int64_t m) {
+    const int64_t total = m * m;
+    const int64_t stride = (int64_t)gridDim.x * FB;
+    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += stride) {
+        const int64_t r = e / m, c = e - r * m;
+        if (c > r) H[e] = H[c * m + r];
+    }
+}
+
+}  // namespace accbpg
+
+using namespace accbpg;
+
+static int fw_alloc(accbpg_dopt* h) {
+    if (h->fw_x) return ACCBPG_OK;
+    ACC_HIP(hipMalloc(&h->fw_x, sizeof(double) * h->n));
+    ACC_HIP(hipMalloc(&h->fw_w, sizeof(double) * h->n));
+    ACC_HIP(hipMalloc(&h->fw_H, sizeof(double) * h->m * h->m));
+    ACC_HIP(hipMalloc(&h->fw_hv, sizeof(double) * 2 * h->m));
+    return ACCBPG_OK;
+}
+
+static int fw_nsplit(const accbpg_dopt* h) {
+    const int64_t colblocks = (h->n + VG_COLS - 1) / VG_COLS;
+    int64_t s = (4 * (int64_t)h->num_cu + colblocks - 1) / colblocks;
+    if (s > VG_MAXSPLIT) s = VG_MAXSPLIT;
+    if (s > h->m / 8) s = h->m / 8;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+static int read_scalars(accbpg_dopt* h, int nd, int ni) {
+    ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * nd, hipMemcpyDeviceToHost, h->stream));
+    ACC_HIP(hipMemcpyAsync(h->hpin + 16, h->dflag, sizeof(int) * ni, hipMemcpyDeviceToHost, h->stream));
+    ACC_HIP(hipStreamSynchronize(h->stream));
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_fw_init(accbpg_dopt* h, const double* x0_dev, double* logdet_gram_host) {
+    if (!h || !x0_dev) return ACCBPG_ERR_ARG;
+    ACC_TRY(fw_alloc(h));
+    const int64_t m = h->m;
+    ACC_HIP(hipMemcpyAsync(h->fw_x, x0_dev, sizeof(double) * h->n, hipMemcpyDeviceToDevice, h->stream));
+    ACC_TRY(launch_gram(h, h->fw_x, h->Lbuf));                 // D_opt_alg.py:40
+    ACC_TRY(launch_cholesky(h, h->Lbuf));                      // det / inv via the Cholesky factor (:41-42)
+    ACC_TRY(read_scalars(h, 1, 4));
+    const int* fl = reinterpret_cast<const int*>(h->hpin + 16);
+    if (fl[FLAG_NOT_PD]) return ACCBPG_ERR_NOT_PD;
+    if (logdet_gram_host) *logdet_gram_host = h->hpin[0];
+    ACC_TRY(launch_trtri(h));                                  // W = L^-1
+    ACC_TRY(launch_colnorm(h, h->Wbuf, h->fw_w, 1.0));         // w_i = |W v_i|^2 = v_i^T H v_i (:45)
+    // H = W^T W: transpose W into Tbuf (rows of W^T are k-contiguous), then one product
+    dim3 tg((unsigned)((m + 31) / 32), (unsigned)((m + 31) / 32));
+    transpose_kernel<<<tg, FB, 0, h->stream>>>(h->Wbuf, h->Tbuf, m);
+    GemmOp op{};
+    op.A = h->Tbuf; op.lda = m; op.B = h->Wbuf; op.ldb = m; op.C = h->fw_H; op.ldc = m;
+    op.M = (int)m; op.N = (int)m; op.K = (int)m; op.lower_only = 1; op.alpha = 1.0; op.beta = 0.0;
+    ACC_HIP(hipMemcpyAsync(h->chol_op, &op, sizeof(GemmOp), hipMemcpyHostToDevice, h->stream));
+    ACC_TRY(launch_gemm_ops(h->chol_op, 1, (int)m, (int)m, true, h->stream));
+    mirror_lower_kernel<<<1024, FB, 0, h->stream>>>(h->fw_H, m);
+    ACC_HIP(hipGetLastError());
+    ACC_HIP(hipStreamSynchronize(h->stream));
+    h->fw_ready = true;
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_fw_probe_step(accbpg_dopt* h, int away, int refresh_logdet, accbpg_fw_probe* out) {
+    if (!h || !out || !h->fw_ready) return ACCBPG_ERR_ARG;
+    const int64_t m = h->m;
+    double logdet = 0.0;
+    if (refresh_logdet) {
+        // F[k] = log det(H) from a fresh factorisation of the maintained inverse (D_opt_alg.py:136)
+        ACC_HIP(hipMemcpyAsync(h->Lbuf, h->fw_H, sizeof(double) * m * m, hipMemcpyDeviceToDevice, h->stream));
+        ACC_TRY(launch_cholesky(h, h->Lbuf));
+        ACC_TRY(read_scalars(h, 1, 4));
+        logdet = h->hpin[0];
+        const int* fl = reinterpret_cast<const int*>(h->hpin + 16);
+        if (fl[FLAG_NOT_PD]) logdet = __builtin_nan("");
+    }
+    int64_t* iout = reinterpret_cast<int64_t*>(h->dscal + 8);
+    fw_probe_kernel<<<1, PROBE_T, 0, h->stream>>>(h->fw_w, h->fw_x, h->n, away, h->dscal + 4, iout);
+    ACC_HIP(hipGetLastError());
+    ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * 12, hipMemcpyDeviceToHost, h->stream));
+    ACC_HIP(hipStreamSynchronize(h->stream));
+    const int64_t* ih = reinterpret_cast<const int64_t*>(h->hpin + 8);
+    out->i = ih[0];
+    out->j = ih[1];
+    out->w_i = h->hpin[4];
+    out->w_j = h->hpin[5];
+    out->x_j = h->hpin[6];
+    out->logdet_H = logdet;
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_fw_update(accbpg_dopt* h, int64_t p, double xscale, double xadd, double hcoef, double hdiv) {
+    if (!h || !h->fw_ready || p < 0 || p >= h->n) return ACCBPG_ERR_ARG;
+    const int64_t m = h->m, n = h->n;
+    double* vp = h->fw_hv + m;
+    int64_t gb = (std::max(n, m) + FB - 1) / FB;
+    if (gb > 1024) gb = 1024;
+    fw_xupdate_gather_kernel<<<(int)gb, FB, 0, h->stream>>>(h->fw_x, n, p, xscale, xadd, h->V, h->ldv, m, vp);
+    fw_gemv_h_kernel<<<(int)((m + FB / 64 - 1) / (FB / 64)), FB, 0, h->stream>>>(h->fw_H, m, vp, h->fw_hv);
+    int64_t rb = (m * m + FB - 1) / FB;
+    if (rb > 4096) rb = 4096;
+    fw_rank1_kernel<<<(int)rb, FB, 0, h->stream>>>(h->fw_H, m, h->fw_hv, hcoef, hdiv);
+    const int ns = fw_nsplit(h);
+    dim3 vg((unsigned)((n + VG_COLS - 1) / VG_COLS), (unsigned)ns);
+    fw_vgemv_partial_kernel<<<vg, FB, 0, h->stream>>>(h->V, h->ldv, m, n, h->fw_hv, ns, h->vws, h->vec_ok);
+    int64_t wb = (n + FB - 1) / FB;
+    if (wb > 2048) wb = 2048;
+    fw_wupdate_kernel<<<(int)wb, FB, 0, h->stream>>>(h->fw_w, n, h->vws, ns, hcoef, hdiv);
+    ACC_HIP(hipGetLastError());
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_fw_get_state(accbpg_dopt* h, double* x_dev, double* w_dev, double* H_dev) {
+    if (!h || !h->fw_ready) return ACCBPG_ERR_ARG;
+    if (x_dev) ACC_HIP(hipMemcpyAsync(x_dev, h->fw_x, sizeof(double) * h->n, hipMemcpyDeviceToDevice, h->stream));
+    if (w_dev) ACC_HIP(hipMemcpyAsync(w_dev, h->fw_w, sizeof(double) * h->n, hipMemcpyDeviceToDevice, h->stream));
+    if (H_dev)
+        ACC_HIP(hipMemcpyAsync(H_dev, h->fw_H, sizeof(double) * h->m * h->m, hipMemcpyDeviceToDevice, h->stream));
+    ACC_HIP(hipStreamSynchronize(h->stream));
+    return ACCBPG_OK;
+}

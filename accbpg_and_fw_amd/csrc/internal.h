@@ -1,0 +1,117 @@
+// Internal declarations shared by the translation units of libaccbpg_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+
+#include "../../include/accbpg_hip.h"
+
+namespace accbpg {
+
+void set_last_error(const char* fmt, ...);
+
+#define ACC_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            ::accbpg::set_last_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call,            \
+                                     hipGetErrorString(e__));                                 \
+            return ACCBPG_ERR_HIP;                                                            \
+        }                                                                                     \
+    } while (0)
+
+#define ACC_TRY(call)                       \
+    do {                                    \
+        int rc__ = (call);                  \
+        if (rc__ != ACCBPG_OK) return rc__; \
+    } while (0)
+
+// one product of the batched small-GEMM kernel: C = alpha * A * op(B) + beta * C
+struct GemmOp {
+    const double* A;
+    const double* B;
+    double* C;
+    int64_t lda, ldb, ldc;
+    int32_t M, N, K;
+    int32_t lower_only;     // skip tiles / elements strictly above the diagonal of C
+    double alpha, beta;
+};
+
+struct TileRC {
+    int32_t rb, cb;
+};
+
+constexpr int NB = 64;          // Cholesky / inverse block size
+constexpr int FLAG_NOT_PD = 0;  // index into the device flag array
+constexpr int FLAG_NEG_X = 1;
+constexpr int FLAG_NONPOS = 2;
+
+enum ProfKind { PROF_GRAM = 0, PROF_CHOL = 1, PROF_TRTRI = 2, PROF_GRAD = 3, PROF_GRAMFIX = 4, PROF_COUNT = 5 };
+
+struct ProfSlot {
+    std::vector<hipEvent_t> ev;   // pairs (start, stop)
+    size_t used = 0;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+}  // namespace accbpg
+
+struct accbpg_dopt {
+    const double* V = nullptr;
+    int64_t m = 0, n = 0, ldv = 0;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    int num_cu = 256;
+    bool big = false;           // use the 256x128 tile for Gram / gradient products
+    bool vec_ok = false;        // V rows are 16-byte aligned
+
+    double* Lbuf = nullptr;     // m*m : Gram matrix, then its Cholesky factor (lower)
+    double* Wbuf = nullptr;     // m*m : inverse of the factor (lower, upper stays zero)
+    double* Tbuf = nullptr;     // m*m : scratch of the inverse merges / FW refactorisation
+    double* slabs = nullptr;    // stream-K partial accumulators
+    accbpg::TileRC* tiles = nullptr;
+    int ntiles = 0, gram_grid = 0, gram_per = 0;
+    int64_t kiters = 0;
+    double* dscal = nullptr;    // device scalars
+    int* dflag = nullptr;       // device status flags
+    double* hpin = nullptr;     // pinned host mirror (scalars then flags)
+    double* vws = nullptr;      // vector-kernel workspace
+
+    accbpg::GemmOp* ops = nullptr;            // device op table of the inverse merges
+    std::vector<accbpg::GemmOp> ops_host;
+    std::vector<int> level_begin;             // ops of level l: [level_begin[l], level_begin[l+1])
+    std::vector<int> level_maxm, level_maxn;
+    accbpg::GemmOp* chol_op = nullptr;        // device slot for the trailing-update op
+
+    // Frank-Wolfe state
+    double *fw_x = nullptr, *fw_w = nullptr, *fw_H = nullptr, *fw_hv = nullptr;
+    bool fw_ready = false;
+
+    bool prof_on = false;
+    accbpg::ProfSlot prof[accbpg::PROF_COUNT];
+};
+
+namespace accbpg {
+
+// dopt_kernels.hip
+int launch_gram(accbpg_dopt* h, const double* x, double* gram);
+int launch_cholesky(accbpg_dopt* h, double* A /* m*m, in place */);
+int launch_trtri(accbpg_dopt* h);
+int launch_colnorm(accbpg_dopt* h, const double* W, double* out, double sign);
+int launch_gemm_ops(const GemmOp* ops_dev, int nops, int maxM, int maxN, bool b_kmajor, hipStream_t s);
+int launch_test_gemm(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                     int64_t M, int64_t N, int64_t K, int b_kmajor, double alpha, double beta, int config,
+                     hipStream_t s);
+int build_plans(accbpg_dopt* h);
+int mfma_peak(int iters, double* tflops, hipStream_t s);
+
+// vec_kernels.hip
+int64_t vec_ws_doubles(int64_t n);
+
+// prof helpers
+void prof_begin(accbpg_dopt* h, ProfKind k);
+void prof_end(accbpg_dopt* h, ProfKind k);
+
+}  // namespace accbpg

@@ -1,0 +1,255 @@
+// fp64 MFMA tile engine for gfx950 (CDNA4).  One workgroup = 256 threads = 4 wave64, one wave
+// per SIMD.  Every product in the D-optimal hot path (weighted Gram matrix, triangular product
+// with column norms, the trailing updates of the Cholesky factorisation, the merges of the
+// triangular inverse) runs through this engine on v_mfma_f64_16x16x4_f64.
+//
+// Operand maps of v_mfma_f64_16x16x4_f64 (cdna_hip_programming.md section 3): lane l supplies
+// A[row = l&15][k = l>>4] and B[k = l>>4][col = l&15]; result register r of lane l is
+// D[row = (l>>4) + 4r][col = l&15].
+//
+// Row fragments are interleaved over the wave rows (fragment i of wave-row wm covers tile rows
+// 16*(i*WAVES_M + wm) .. +15) so that a triangular operand loads every wave equally.
+//
+// LDS images (BK = 16 doubles deep):
+//   k-contiguous operand  : [rows][BK+2]   -- stride 18 doubles makes the 32-lane group of a
+//                           ds_read_b64 (16 rows x 2 k) hit 64 distinct banks;
+//   k-major (B[k][col])   : [BK][cols+16]  -- lanes 0-15 read one 128-B row segment, lanes 16-31
+//                           the next k, offset by 2*(cols+16) = 32 (mod 64) banks.
+// Staging is global -> registers -> LDS, double buffered, one barrier per 16-deep step: the
+// fp64 MFMA takes 64 cycles per instruction per SIMD, so a 64x128 wave tile spends 8192 cycles
+// of matrix work per step and a one-step-ahead register prefetch covers an HBM miss.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace accbpg {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int BK = 16;
+constexpr int SK = BK + 2;          // LDS row stride (doubles) of a k-contiguous image
+constexpr int NTHREADS = 256;
+
+__device__ __forceinline__ d2 load2_guard(const double* __restrict__ p, bool row_ok, int64_t k, int64_t K,
+                                          bool vec_ok) {
+    d2 v;
+    if (row_ok && vec_ok && k + 1 < K) {
+        v = *reinterpret_cast<const d2*>(p);
+    } else {
+        v.x = (row_ok && k < K) ? p[0] : 0.0;
+        v.y = (row_ok && k + 1 < K) ? p[1] : 0.0;
+    }
+    return v;
+}
+
+// BM x BN workgroup tile, WM x WN wave tile, B either k-major (B[k][col], "NN") or
+// k-contiguous (B[col][k], "NT").
+// EDGE = false promises: every tile is interior (row/col/k extents are multiples of the tile and
+// of BK) and every operand row is 16-byte aligned, so staging loads are unguarded 16-byte loads.
+template <int BM_, int BN_, int WM_, int WN_, bool BKM_, bool EDGE_ = true>
+struct Tile {
+    static constexpr bool EDGE = EDGE_;
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr bool BKM = BKM_;
+    static constexpr int WAVES_M = BM / WM, WAVES_N = BN / WN;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static constexpr int MI = WM / 16, NI = WN / 16;
+    static constexpr int SBN = BN + 16;                         // stride of a k-major B image
+    static constexpr int A_ELEMS = BM * SK;
+    static constexpr int B_ELEMS = BKM ? BK * SBN : BN * SK;
+    static constexpr int STAGE_ELEMS = A_ELEMS + B_ELEMS;
+    static constexpr int LDS_BYTES = 2 * STAGE_ELEMS * 8;
+    static constexpr int A_PASS = BM / 32;                      // 16-B chunks per thread, A
+    static constexpr int BKM_TPR = BN / 2;                      // threads per k-row, k-major B
+    static constexpr int BKM_RPP = NTHREADS / BKM_TPR;          // k-rows per pass
+    static constexpr int B_PASS = BKM ? BK / BKM_RPP : BN / 32;
+    static_assert(!BKM || (BK % BKM_RPP == 0), "k-major staging shape");
+
+    d4 acc[MI][NI];
+    d2 ra[A_PASS];
+    d2 rb[B_PASS];
+
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+    }
+
+    // ---- global -> registers -------------------------------------------------------------
+    // A: rows [row0, row0+BM) of a k-contiguous matrix (lda), columns [k0, k0+16).
+    __device__ __forceinline__ void gload_A(const double* __restrict__ A, int64_t lda, int64_t row0, int64_t M,
+                                            int64_t k0, int64_t K, bool vec_ok) {
+        const int tid = threadIdx.x;
+        const int c = tid & 7, r = tid >> 3;
+        const int64_t k = k0 + 2 * c;
+        if constexpr (!EDGE) {
+            const double* __restrict__ base = A + (row0 + r) * lda + k;
+#pragma unroll
+            for (int p = 0; p < A_PASS; ++p) ra[p] = *reinterpret_cast<const d2*>(base + (int64_t)(32 * p) * lda);
+        } else {
+#pragma unroll
+            for (int p = 0; p < A_PASS; ++p) {
+                const int64_t row = row0 + r + 32 * p;
+                ra[p] = load2_guard(A + row * lda + k, row < M, k, K, vec_ok);
+            }
+        }
+    }
+    // scale the staged A chunk by x[k], x[k+1] (weighted Gram matrix: (V*x) of functions.py:46)
+    __device__ __forceinline__ void scale_A(const double* __restrict__ x, int64_t k0, int64_t K) {
+        const int c = threadIdx.x & 7;
+        const int64_t k = k0 + 2 * c;
+        double x0, x1;
+        if constexpr (!EDGE) {
+            const d2 xv = *reinterpret_cast<const d2*>(x + k);
+            x0 = xv.x; x1 = xv.y;
+        } else {
+            x0 = (k < K) ? x[k] : 0.0;
+            x1 = (k + 1 < K) ? x[k + 1] : 0.0;
+        }
+#pragma unroll
+        for (int p = 0; p < A_PASS; ++p) {
+            ra[p].x *= x0;
+            ra[p].y *= x1;
+        }
+    }
+    // B k-contiguous: rows (= output columns) [col0, col0+BN) of B[col][k].
+    __device__ __forceinline__ void gload_B_kc(const double* __restrict__ B, int64_t ldb, int64_t col0, int64_t N,
+                                               int64_t k0, int64_t K, bool vec_ok) {
+        const int tid = threadIdx.x;
+        const int c = tid & 7, r = tid >> 3;
+        const int64_t k = k0 + 2 * c;
+        if constexpr (!EDGE) {
+            const double* __restrict__ base = B + (col0 + r) * ldb + k;
+#pragma unroll
+            for (int p = 0; p < B_PASS; ++p) rb[p] = *reinterpret_cast<const d2*>(base + (int64_t)(32 * p) * ldb);
+        } else {
+#pragma unroll
+            for (int p = 0; p < B_PASS; ++p) {
+                const int64_t row = col0 + r + 32 * p;
+                rb[p] = load2_guard(B + row * ldb + k, row < N, k, K, vec_ok);
+            }
+        }
+    }
+    // B k-major: rows [k0, k0+16) of B[k][col], columns [col0, col0+BN).
+    __device__ __forceinline__ void gload_B_km(const double* __restrict__ B, int64_t ldb, int64_t col0, int64_t N,
+                                               int64_t k0, int64_t K, bool vec_ok) {
+        const int tid = threadIdx.x;
+        const int c = 2 * (tid % BKM_TPR), r = tid / BKM_TPR;
+        const int64_t col = col0 + c;
+        if constexpr (!EDGE) {
+            const double* __restrict__ base = B + (k0 + r) * ldb + col;
+#pragma unroll
+            for (int p = 0; p < B_PASS; ++p)
+                rb[p] = *reinterpret_cast<const d2*>(base + (int64_t)(BKM_RPP * p) * ldb);
+        } else {
+#pragma unroll
+            for (int p = 0; p < B_PASS; ++p) {
+                const int64_t k = k0 + r + BKM_RPP * p;
+                rb[p] = load2_guard(B + k * ldb + col, k < K, col, N, vec_ok);
+            }
+        }
+    }
+
+    // ---- registers -> LDS ----------------------------------------------------------------
+    __device__ __forceinline__ void sstore(double* __restrict__ stage) {
+        const int tid = threadIdx.x;
+        {
+            const int c = tid & 7, r = tid >> 3;
+#pragma unroll
+            for (int p = 0; p < A_PASS; ++p)
+                *reinterpret_cast<d2*>(stage + (r + 32 * p) * SK + 2 * c) = ra[p];
+        }
+        double* bs = stage + A_ELEMS;
+        if constexpr (BKM) {
+            const int c = 2 * (tid % BKM_TPR), r = tid / BKM_TPR;
+#pragma unroll
+            for (int p = 0; p < B_PASS; ++p)
+                *reinterpret_cast<d2*>(bs + (r + BKM_RPP * p) * SBN + c) = rb[p];
+        } else {
+            const int c = tid & 7, r = tid >> 3;
+#pragma unroll
+            for (int p = 0; p < B_PASS; ++p)
+                *reinterpret_cast<d2*>(bs + (r + 32 * p) * SK + 2 * c) = rb[p];
+        }
+    }
+
+    // ---- LDS -> MFMA ---------------------------------------------------------------------
+    // mi_lo: first 16-row fragment of this wave that can be non-zero (triangular skip), [mi_lo, MI).
+    __device__ __forceinline__ void compute(const double* __restrict__ stage, int mi_lo = 0) {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+        const int lr = lane & 15, lq = lane >> 4;
+        const double* as = stage + (16 * wm + lr) * SK + lq;   // fragment i of wave-row wm = rows 16*(i*WAVES_M+wm)..+15
+        const double* bs = stage + A_ELEMS + (BKM ? (lq * SBN + wn * WN + lr) : ((wn * WN + lr) * SK + lq));
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            double a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = as[i * 16 * WAVES_M * SK + 4 * kk];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) b[j] = BKM ? bs[4 * kk * SBN + 16 * j] : bs[j * 16 * SK + 4 * kk];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                if (i >= mi_lo) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogues -----------------------------------------------------------------------
+    // C[row][col] = alpha*acc + beta*C, guarded; lower_only drops elements with col > row.
+    __device__ __forceinline__ void store_C(double* __restrict__ C, int64_t ldc, int64_t row0, int64_t col0,
+                                            int64_t M, int64_t N, double alpha, double beta, bool lower_only) const {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+        const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = row0 + 16 * (i * WAVES_M + wm) + lq + 4 * r;
+                    const int64_t col = col0 + wn * WN + 16 * j + lr;
+                    if ((!EDGE || (row < M && col < N)) && !(lower_only && col > row)) {
+                        double* p = C + row * ldc + col;
+                        double v = alpha * acc[i][j][r];
+                        if (beta != 0.0) v += beta * *p;
+                        *p = v;
+                    }
+                }
+    }
+    // raw accumulator slab (stream-K partials): [MI*NI*4][256] doubles, coalesced per register.
+    __device__ __forceinline__ void store_slab(double* __restrict__ slab) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[((i * NI + j) * 4 + r) * NTHREADS + tid] = acc[i][j][r];
+    }
+    __device__ __forceinline__ void add_slab(const double* __restrict__ slab) {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += slab[((i * NI + j) * 4 + r) * NTHREADS + tid];
+    }
+    static constexpr int SLAB_DOUBLES = MI * NI * 4 * NTHREADS;   // == BM*BN
+};
+
+// The two instantiated shapes: "big" fills one CU with a 256x128 tile (wave tile 64x128, 256
+// accumulator VGPRs, one workgroup per CU); "small" is a 64x64 tile for the latency-bound
+// pieces (Cholesky trailing updates, inverse merges, small instances).
+template <bool BKM, bool EDGE = true> using TileBig = Tile<256, 128, 64, 128, BKM, EDGE>;
+template <bool BKM, bool EDGE = true> using TileSmall = Tile<64, 64, 32, 32, BKM, EDGE>;
+
+}  // namespace accbpg

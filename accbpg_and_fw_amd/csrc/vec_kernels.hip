@@ -1,0 +1,377 @@
+// Length-n kernels of the Bregman proximal gradient loop on gfx950: Burg-entropy simplex prox
+// (the whole bisection + Newton scalar solve in one launch), Bregman divergences, the line-search
+// inner product, and the a*x + b*z combination.  HBM/latency-bound: coalesced 8-byte-per-lane
+// streams, wavefront (64-lane) shuffle reductions, a fixed reduction tree so that results are
+// reproducible run to run.
+//
+// This translation unit is compiled with -ffp-contract=off: the reference evaluates these
+// expressions with separate NumPy ufuncs (one rounding per operation), so no multiply-add here
+// may be fused.  Replaces accbpg/functions.py:246-271 and 336-356.
+#include "internal.h"
+
+namespace accbpg {
+
+constexpr int PB = 1024;   // threads of the single-workgroup prox kernel
+constexpr int RB = 256;    // threads of the streaming reductions
+constexpr int RMAXBLK = 1024;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off));
+    return v;
+}
+
+// sum over the PB threads of the prox workgroup, result broadcast to every thread
+__device__ __forceinline__ double block_sum_bcast(double v, double* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < PB / 64; ++i) s += sh[i];
+    return s;
+}
+__device__ __forceinline__ double block_min_bcast(double v, double* sh) {
+    v = wave_min(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double s = sh[0];
+#pragma unroll
+    for (int i = 1; i < PB / 64; ++i) s = fmin(s, sh[i]);
+    return s;
+}
+
+// Burg simplex prox, functions.py:336-356 (and :264-271 when y != NULL).
+// EPT > 0: gg lives in registers (n <= PB*EPT); EPT == 0: gg is kept in `ggbuf` and re-read.
+template <int EPT>
+__global__ __launch_bounds__(PB) void burg_prox_kernel(const double* __restrict__ y, const double* __restrict__ g,
+                                                      double L, double eps, int64_t n, double* __restrict__ xout,
+                                                      double* __restrict__ ggbuf, int* __restrict__ info,
+                                                      int* __restrict__ flags) {
+    __shared__ double sh[PB / 64];
+    const int tid = threadIdx.x;
+    constexpr int R = EPT > 0 ? EPT : 1;
+    double gg[R];
+    const double inf = __builtin_inf();
+    double lmin = inf;
+    bool bad = false;
+
+    auto make_gg = [&](int64_t i) -> double {
+        double a = g[i];
+        if (y != nullptr) {
+            const double yi = y[i];
+            if (!(yi > 0.0)) bad = true;
+            const double t = -1.0 / yi;       // h.gradient(y)      functions.py:248
+            a = a - L * t;                    // g - L*grad         functions.py:271
+        }
+        return a / L;                         // gg = g / L         functions.py:341
+    };
+    if constexpr (EPT > 0) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int64_t i = tid + (int64_t)PB * e;
+            gg[e] = (i < n) ? make_gg(i) : inf;
+            lmin = fmin(lmin, gg[e]);
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += PB) {
+            const double v = make_gg(i);
+            ggbuf[i] = v;
+            lmin = fmin(lmin, v);
+        }
+    }
+    const double cmin = -block_min_bcast(lmin, sh);       // functions.py:342
+
+    auto phi = [&](double c) -> double {                   // sum(1/(gg+c)) - 1
+        double s = 0.0;
+        if constexpr (EPT > 0) {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) s += 1.0 / (gg[e] + c);
+        } else {
+            for (int64_t i = tid; i < n; i += PB) s += 1.0 / (ggbuf[i] + c);
+        }
+        return block_sum_bcast(s, sh) - 1.0;
+    };
+    auto dphi = [&](double c) -> double {                  // sum(-1/(gg+c)^2)
+        double s = 0.0;
+        if constexpr (EPT > 0) {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const double r = gg[e] + c;
+                s += -1.0 / (r * r);
+            }
+        } else {
+            for (int64_t i = tid; i < n; i += PB) {
+                const double r = ggbuf[i] + c;
+                s += -1.0 / (r * r);
+            }
+        }
+        return block_sum_bcast(s, sh);
+    };
+
+    double c = cmin + 1.0;                                 // functions.py:344
+    int nb = 0, nn = 0;
+    double fc = phi(c);
+    while (fc < 0.0 && nb < 4096) {                        // functions.py:345-346
+        c = (cmin + c) / 2.0;
+        fc = phi(c);
+        ++nb;
+    }
+    while (fabs(fc) > eps && nn < 4096) {                  // functions.py:349
+        const double fpc = dphi(c);                        // :350
+        const double step = fc / fpc;
+        if ((c - (c - step)) == 0.0) break;                // :351-352
+        c = c - step;                                      // :353
+        fc = phi(c);                                       // :354
+        ++nn;
+    }
+    if constexpr (EPT > 0) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int64_t i = tid + (int64_t)PB * e;
+            if (i < n) xout[i] = 1.0 / (gg[e] + c);        // :355
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += PB) xout[i] = 1.0 / (ggbuf[i] + c);
+    }
+    if (bad) flags[FLAG_NONPOS] = 1;
+    if (tid == 0) {
+        info[0] = nb;
+        info[1] = nn;
+    }
+}
+
+// Streaming reduction, stage 1.  Up to four sums / minima per pass:
+//   q0 = sum g*(x-y)                                  (np.dot(g, x1-x), algorithms.py:53)
+//   q1 = sum x/y - log(x/y) - 1                       (functions.py:253)
+//   q2 = sum z/z1 - log(z/z1) - 1
+//   q3 = min over every vector that enters a divergence (positivity assert, functions.py:252)
+__global__ __launch_bounds__(RB) void ls_terms_partial_kernel(const double* __restrict__ g,
+                                                             const double* __restrict__ x,
+                                                             const double* __restrict__ y,
+                                                             const double* __restrict__ z,
+                                                             const double* __restrict__ z1, int64_t n,
+                                                             int want_div_xy, double* __restrict__ part) {
+    __shared__ double sh[4][RB / 64];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, mn = __builtin_inf();
+    const int64_t stride = (int64_t)gridDim.x * RB;
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
+        if (x != nullptr && y != nullptr) {
+            const double xi = x[i], yi = y[i];
+            if (g != nullptr) {
+                const double d = xi - yi;
+                s0 += g[i] * d;
+            }
+            if (want_div_xy) {
+                const double r = xi / yi;
+                s1 += r - log(r) - 1.0;
+                mn = fmin(mn, fmin(xi, yi));
+            }
+        }
+        if (z != nullptr) {
+            const double zi = z[i], wi = z1[i];
+            const double r = zi / wi;
+            s2 += r - log(r) - 1.0;
+            mn = fmin(mn, fmin(zi, wi));
+        }
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); mn = wave_min(mn);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][w] = s0; sh[1][w] = s1; sh[2][w] = s2; sh[3][w] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0, c = 0.0, d = sh[3][0];
+        for (int i = 0; i < RB / 64; ++i) { a += sh[0][i]; b += sh[1][i]; c += sh[2][i]; d = fmin(d, sh[3][i]); }
+        part[blockIdx.x * 4 + 0] = a; part[blockIdx.x * 4 + 1] = b;
+        part[blockIdx.x * 4 + 2] = c; part[blockIdx.x * 4 + 3] = d;
+    }
+}
+
+// stage 2: one workgroup adds the partials in block order
+__global__ __launch_bounds__(RB) void ls_terms_final_kernel(const double* __restrict__ part, int nblk,
+                                                           double* __restrict__ out) {
+    __shared__ double sh[4][RB / 64];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, mn = __builtin_inf();
+    for (int b = threadIdx.x; b < nblk; b += RB) {
+        s0 += part[b * 4 + 0]; s1 += part[b * 4 + 1]; s2 += part[b * 4 + 2];
+        mn = fmin(mn, part[b * 4 + 3]);
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); mn = wave_min(mn);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][w] = s0; sh[1][w] = s1; sh[2][w] = s2; sh[3][w] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0, c = 0.0, d = sh[3][0];
+        for (int i = 0; i < RB / 64; ++i) { a += sh[0][i]; b += sh[1][i]; c += sh[2][i]; d = fmin(d, sh[3][i]); }
+        out[0] = a; out[1] = b; out[2] = c; out[3] = d;
+    }
+}
+
+__global__ __launch_bounds__(RB) void min_sum_partial_kernel(const double* __restrict__ x, int64_t n,
+                                                            double* __restrict__ part) {
+    __shared__ double sh[2][RB / 64];
+    double s = 0.0, mn = __builtin_inf();
+    const int64_t stride = (int64_t)gridDim.x * RB;
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
+        const double v = x[i];
+        s += v;
+        mn = fmin(mn, v);
+    }
+    s = wave_sum(s); mn = wave_min(mn);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sh[0][w] = s; sh[1][w] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, d = sh[1][0];
+        for (int i = 0; i < RB / 64; ++i) { a += sh[0][i]; d = fmin(d, sh[1][i]); }
+        part[blockIdx.x * 4 + 0] = a; part[blockIdx.x * 4 + 1] = 0.0;
+        part[blockIdx.x * 4 + 2] = 0.0; part[blockIdx.x * 4 + 3] = d;
+    }
+}
+
+// out = a*x + b*z with NumPy's rounding of (1-theta)*x + theta*z   (algorithms.py:147,150,369,374)
+__global__ __launch_bounds__(RB) void axpby_kernel(double a, const double* __restrict__ x, double b,
+                                                  const double* __restrict__ z, int64_t n,
+                                                  double* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * RB;
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
+        const double p = a * x[i];
+        const double q = b * z[i];
+        out[i] = p + q;
+    }
+}
+
+// -----------------------------------------------------------------------------------------
+static double* g_pin = nullptr;       // pinned host scratch (16 doubles)
+static int* g_flags = nullptr;        // device flags for the handle-free entry points
+static int* g_info = nullptr;         // device {bisection, newton}
+static double* g_out = nullptr;       // device result scalars
+
+static int ensure_scratch() {
+    if (g_pin) return ACCBPG_OK;
+    ACC_HIP(hipHostMalloc(&g_pin, 32 * sizeof(double), hipHostMallocDefault));
+    ACC_HIP(hipMalloc(&g_flags, 8 * sizeof(int)));
+    ACC_HIP(hipMalloc(&g_info, 8 * sizeof(int)));
+    ACC_HIP(hipMalloc(&g_out, 16 * sizeof(double)));
+    return ACCBPG_OK;
+}
+
+int64_t vec_ws_doubles(int64_t n) { return n + 4 * RMAXBLK + 64; }
+
+static int red_blocks(int64_t n) {
+    int64_t b = (n + (int64_t)RB * 4 - 1) / ((int64_t)RB * 4);
+    if (b < 1) b = 1;
+    if (b > RMAXBLK) b = RMAXBLK;
+    return (int)b;
+}
+
+}  // namespace accbpg
+
+using namespace accbpg;
+
+extern "C" int64_t accbpg_vec_workspace_doubles(int64_t n) { return vec_ws_doubles(n); }
+
+extern "C" int accbpg_burg_simplex_div_prox(const double* y_dev, const double* g_dev, double L, double eps,
+                                            int64_t n, double* x_out_dev, double* ws_dev, int* info_host,
+                                            void* stream) {
+    if (!g_dev || !x_out_dev || n <= 0 || !ws_dev) return ACCBPG_ERR_ARG;
+    if (!(L > 0.0)) return ACCBPG_ERR_ASSERT;                 // functions.py:270 / :340
+    ACC_TRY(ensure_scratch());
+    hipStream_t s = (hipStream_t)stream;
+    ACC_HIP(hipMemsetAsync(g_flags, 0, 8 * sizeof(int), s));
+    if (n <= (int64_t)PB * 2)
+        burg_prox_kernel<2><<<1, PB, 0, s>>>(y_dev, g_dev, L, eps, n, x_out_dev, ws_dev, g_info, g_flags);
+    else if (n <= (int64_t)PB * 8)
+        burg_prox_kernel<8><<<1, PB, 0, s>>>(y_dev, g_dev, L, eps, n, x_out_dev, ws_dev, g_info, g_flags);
+    else if (n <= (int64_t)PB * 32)
+        burg_prox_kernel<32><<<1, PB, 0, s>>>(y_dev, g_dev, L, eps, n, x_out_dev, ws_dev, g_info, g_flags);
+    else
+        burg_prox_kernel<0><<<1, PB, 0, s>>>(y_dev, g_dev, L, eps, n, x_out_dev, ws_dev, g_info, g_flags);
+    ACC_HIP(hipGetLastError());
+    int* pin_i = reinterpret_cast<int*>(g_pin);
+    ACC_HIP(hipMemcpyAsync(pin_i, g_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    ACC_HIP(hipMemcpyAsync(pin_i + 4, g_info, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    ACC_HIP(hipStreamSynchronize(s));
+    if (info_host) { info_host[0] = pin_i[4]; info_host[1] = pin_i[5]; }
+    if (pin_i[FLAG_NONPOS]) return ACCBPG_ERR_ASSERT;         // y.min() > 0, functions.py:270
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_ls_terms(const double* g_dev, const double* x_dev, const double* y_dev, const double* z_dev,
+                               const double* z1_dev, int64_t n, double* out_host, double* ws_dev, void* stream) {
+    if (n <= 0 || !out_host || !ws_dev) return ACCBPG_ERR_ARG;
+    if ((z_dev == nullptr) != (z1_dev == nullptr)) return ACCBPG_ERR_ARG;
+    ACC_TRY(ensure_scratch());
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = red_blocks(n);
+    double* part = ws_dev + n;
+    ls_terms_partial_kernel<<<nb, RB, 0, s>>>(g_dev, x_dev, y_dev, z_dev, z1_dev, n, 1, part);
+    ls_terms_final_kernel<<<1, RB, 0, s>>>(part, nb, g_out);
+    ACC_HIP(hipGetLastError());
+    ACC_HIP(hipMemcpyAsync(g_pin + 8, g_out, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+    ACC_HIP(hipStreamSynchronize(s));
+    out_host[0] = g_pin[8]; out_host[1] = g_pin[9]; out_host[2] = g_pin[10];
+    if (!(g_pin[11] > 0.0)) return ACCBPG_ERR_ASSERT;         // functions.py:252
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_burg_divergence(const double* x_dev, const double* y_dev, int64_t n, double* out_host,
+                                      double* ws_dev, void* stream) {
+    if (!x_dev || !y_dev) return ACCBPG_ERR_ARG;
+    double o[3];
+    int rc = accbpg_ls_terms(nullptr, x_dev, y_dev, nullptr, nullptr, n, o, ws_dev, stream);
+    if (out_host) out_host[0] = o[1];
+    return rc;
+}
+
+extern "C" int accbpg_vec_dot_diff(const double* g_dev, const double* x_dev, const double* y_dev, int64_t n,
+                                   double* out_host, double* ws_dev, void* stream) {
+    if (!g_dev || !x_dev || !y_dev || n <= 0 || !out_host || !ws_dev) return ACCBPG_ERR_ARG;
+    ACC_TRY(ensure_scratch());
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = red_blocks(n);
+    double* part = ws_dev + n;
+    ls_terms_partial_kernel<<<nb, RB, 0, s>>>(g_dev, x_dev, y_dev, nullptr, nullptr, n, 0, part);
+    ls_terms_final_kernel<<<1, RB, 0, s>>>(part, nb, g_out);
+    ACC_HIP(hipGetLastError());
+    ACC_HIP(hipMemcpyAsync(g_pin + 8, g_out, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+    ACC_HIP(hipStreamSynchronize(s));
+    out_host[0] = g_pin[8];
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_vec_min_sum(const double* x_dev, int64_t n, double* out_host, double* ws_dev, void* stream) {
+    if (!x_dev || n <= 0 || !out_host || !ws_dev) return ACCBPG_ERR_ARG;
+    ACC_TRY(ensure_scratch());
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = red_blocks(n);
+    double* part = ws_dev + n;
+    min_sum_partial_kernel<<<nb, RB, 0, s>>>(x_dev, n, part);
+    ls_terms_final_kernel<<<1, RB, 0, s>>>(part, nb, g_out);
+    ACC_HIP(hipGetLastError());
+    ACC_HIP(hipMemcpyAsync(g_pin + 8, g_out, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+    ACC_HIP(hipStreamSynchronize(s));
+    out_host[0] = g_pin[11];
+    out_host[1] = g_pin[8];
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_vec_axpby(double a, const double* x_dev, double b, const double* z_dev, int64_t n,
+                                double* out_dev, void* stream) {
+    if (!x_dev || !z_dev || !out_dev || n <= 0) return ACCBPG_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    int64_t nb = (n + RB - 1) / RB;
+    if (nb > 2048) nb = 2048;
+    axpby_kernel<<<(int)nb, RB, 0, s>>>(a, x_dev, b, z_dev, n, out_dev);
+    ACC_HIP(hipGetLastError());
+    return ACCBPG_OK;
+}

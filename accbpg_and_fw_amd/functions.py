@@ -1,0 +1,316 @@
+"""Device-backed mirror of the f / h object protocol of the reference
+(accbpg/functions.py:10-59, 199-271, 326-356).
+
+Same class names, method names, argument meaning and exceptions, so the
+reference's own solver loops (and this package's) can call them unchanged.
+Vectors may be NumPy arrays (copied to the GPU and results copied back, for
+drop-in use from NumPy drivers) or fp64 CUDA tensors (kept on the device, the
+fast path used by this package's solvers).  All arithmetic runs in
+libaccbpg_hip.so; torch only owns memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+# ------------------------------------------------------------------ helpers
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("accbpg_and_fw_amd needs an AMD GPU (torch.cuda is not available); "
+                           "there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def to_dev(a):
+    """-> (fp64 contiguous CUDA tensor, came_from_numpy)."""
+    if isinstance(a, torch.Tensor):
+        if a.dtype != torch.float64:
+            a = a.to(torch.float64)
+        if not a.is_cuda:
+            return a.to(_device()).contiguous(), False
+        return a.contiguous(), False
+    arr = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    return torch.from_numpy(arr).to(_device()), True
+
+
+def from_dev(t, as_numpy):
+    return t.cpu().numpy() if as_numpy else t
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class _Workspace:
+    """Scratch for the length-n kernels, one per (device, n)."""
+    _cache = {}
+
+    @classmethod
+    def get(cls, n, device):
+        key = (device.index, int(n))
+        ws = cls._cache.get(key)
+        if ws is None:
+            size = _lib.load().accbpg_vec_workspace_doubles(int(n))
+            ws = torch.empty(size, dtype=torch.float64, device=device)
+            cls._cache[key] = ws
+        return ws
+
+
+# ------------------------------------------------------------------ f
+class RSmoothFunction:
+    """Relatively-smooth function protocol (accbpg/functions.py:10-24)."""
+
+    def __call__(self, x):
+        assert 0, "RSmoothFunction: __call__(x) is not defined"
+
+    def gradient(self, x):
+        assert 0, "RSmoothFunction: gradient(x) is not defined"
+
+    def func_grad(self, x, flag):
+        assert 0, "RSmoothFunction: func_grad(x, flag) is not defined"
+
+
+class DOptimalObj(RSmoothFunction):
+    """f(x) = -log det(H diag(x) H^T), H m x n with m < n  (accbpg/functions.py:27-59).
+
+    ``H`` may be a NumPy array (copied to the GPU once) or an fp64 CUDA tensor
+    (borrowed).  ``self.H``, ``self.m``, ``self.n`` stay readable as in the
+    reference (callers use ``f.H``)."""
+
+    def __init__(self, H):
+        self.H = H
+        self.m = H.shape[0]
+        self.n = H.shape[1]
+        assert self.m < self.n, "DOptimalObj: need m < n"
+        self._V, _ = to_dev(H)
+        lib = _lib.load()
+        h = C.c_void_p()
+        with torch.cuda.device(self._V.device):
+            rc = lib.accbpg_dopt_create(_ptr(self._V), self.m, self.n, self._V.stride(0), _stream(), C.byref(h))
+        _lib.check(rc, "accbpg_dopt_create")
+        self._h = h
+        self._lib = lib
+        self.calls = {"value": 0, "grad": 0}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self._lib.accbpg_dopt_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    @property
+    def device(self):
+        return self._V.device
+
+    @property
+    def V_dev(self):
+        return self._V
+
+    def __call__(self, x):
+        return self.func_grad(x, flag=0)
+
+    def gradient(self, x):
+        return self.func_grad(x, flag=1)
+
+    def func_grad(self, x, flag=2):
+        """flag=0: function, flag=1: gradient, flag=2: function & gradient."""
+        assert (x.numel() if isinstance(x, torch.Tensor) else x.size) == self.n, \
+            "DOptimalObj: x.size not equal to n"
+        xd, was_np = to_dev(x)
+        fval = C.c_double(0.0)
+        g = None
+        with torch.cuda.device(self._V.device):
+            self._lib.accbpg_dopt_set_stream(self._h, _stream())
+            if flag != 0:
+                g = torch.empty(self.n, dtype=torch.float64, device=self._V.device)
+            rc = self._lib.accbpg_dopt_func_grad(self._h, _ptr(xd), int(flag), C.byref(fval), _ptr(g))
+        _lib.check(rc, "accbpg_dopt_func_grad", "DOptimalObj: x needs to be nonnegative")
+        self.calls["value" if flag == 0 else "grad"] += 1
+        if flag == 0:
+            return fval.value
+        g = from_dev(g, was_np)
+        return g if flag == 1 else (fval.value, g)
+
+    # ---- staged evaluation for design-point sharding ----
+    def gram_into(self, x_dev, gram_dev):
+        with torch.cuda.device(self._V.device):
+            self._lib.accbpg_dopt_set_stream(self._h, _stream())
+            rc = self._lib.accbpg_dopt_gram(self._h, _ptr(x_dev), _ptr(gram_dev))
+        _lib.check(rc, "accbpg_dopt_gram")
+
+    def factor(self, gram_dev):
+        fval = C.c_double(0.0)
+        with torch.cuda.device(self._V.device):
+            rc = self._lib.accbpg_dopt_factor(self._h, _ptr(gram_dev), C.byref(fval))
+        _lib.check(rc, "accbpg_dopt_factor")
+        return fval.value
+
+    def grad_from_factor(self, g_dev):
+        with torch.cuda.device(self._V.device):
+            rc = self._lib.accbpg_dopt_grad(self._h, _ptr(g_dev))
+        _lib.check(rc, "accbpg_dopt_grad")
+
+    # ---- kernel-time accounting used by bench.py ----
+    def profile(self, enable=True):
+        self._lib.accbpg_dopt_profile_enable(self._h, 1 if enable else 0)
+        self._lib.accbpg_dopt_profile_reset(self._h)
+
+    def profile_read(self):
+        out = {}
+        for idx, name in enumerate(["gram", "cholesky", "trtri", "grad", "gram_fixup"]):
+            ms, cnt = C.c_double(0.0), C.c_int64(0)
+            self._lib.accbpg_dopt_profile_read(self._h, idx, C.byref(ms), C.byref(cnt))
+            out[name] = (ms.value, cnt.value)
+        return out
+
+
+# ------------------------------------------------------------------ h
+class LegendreFunction:
+    """Legendre kernel protocol (accbpg/functions.py:199-235)."""
+
+    def __call__(self, x):
+        assert 0, "LegendreFunction: __call__(x) is not defined."
+
+    def extra_Psi(self, x):
+        return 0
+
+    def gradient(self, x):
+        assert 0, "LegendreFunction: gradient(x) is not defined."
+
+    def divergence(self, x, y):
+        assert 0, "LegendreFunction: divergence(x,y) is not defined."
+
+    def prox_map(self, g, L):
+        assert 0, "LegendreFunction: prox_map(x, L) is not defined."
+
+    def div_prox_map(self, y, g, L):
+        assert y.shape == g.shape, "Vectors y and g should have same size."
+        assert L > 0, "Relative smoothness constant L should be positive."
+        return self.prox_map(g - L * self.gradient(y), L)
+
+
+class BurgEntropy(LegendreFunction):
+    """h(x) = -sum log x_i  (accbpg/functions.py:238-271)."""
+
+    def __call__(self, x):
+        # off the solver path (no solver calls h(x)); evaluated with torch on the device
+        xd, _ = to_dev(x)
+        assert float(xd.min()) > 0, "BurgEntropy only takes positive arguments."
+        return float(-torch.log(xd).sum())
+
+    def gradient(self, x):
+        xd, was_np = to_dev(x)
+        assert float(xd.min()) > 0, "BurgEntropy only takes positive arguments."
+        return from_dev(-1.0 / xd, was_np)
+
+    def divergence(self, x, y):
+        assert x.shape == y.shape, "Vectors x and y are of different sizes."
+        xd, _ = to_dev(x)
+        yd, _ = to_dev(y)
+        n = xd.numel()
+        out = C.c_double(0.0)
+        with torch.cuda.device(xd.device):
+            ws = _Workspace.get(n, xd.device)
+            rc = _lib.load().accbpg_burg_divergence(_ptr(xd), _ptr(yd), n, C.byref(out), _ptr(ws), _stream())
+        _lib.check(rc, "accbpg_burg_divergence", "Entries of x or y not positive.")
+        return out.value
+
+    def prox_map(self, g, L):
+        assert L > 0, "BurgEntropy prox_map only takes positive L value."
+        gd, was_np = to_dev(g)
+        assert float(gd.min()) > 0, "BurgEntropy prox_map only takes positive value."
+        return from_dev(L / gd, was_np)
+
+    def div_prox_map(self, y, g, L):
+        assert y.shape == g.shape, "Vectors y and g are of different sizes."
+        yd, was_np = to_dev(y)
+        assert float(yd.min()) > 0 and L > 0, "Either y or L is not positive."
+        gd, _ = to_dev(g)
+        res = self.prox_map(gd - L * (-1.0 / yd), L)
+        return from_dev(res, was_np)
+
+
+class BurgEntropySimplex(BurgEntropy):
+    r"""Burg entropy with the unit-simplex constraint (accbpg/functions.py:326-356)."""
+
+    def __init__(self, eps=1e-8):
+        assert eps > 0, "BurgEntropySimplex: eps should be positive."
+        self.eps = eps
+        self.last_info = (0, 0)     # (bisection steps, Newton steps) of the last prox
+
+    def _prox(self, y, g, L):
+        gd, was_np = to_dev(g)
+        yd = None
+        if y is not None:
+            yd, _ = to_dev(y)
+        n = gd.numel()
+        out = torch.empty(n, dtype=torch.float64, device=gd.device)
+        info = (C.c_int * 2)(0, 0)
+        with torch.cuda.device(gd.device):
+            ws = _Workspace.get(n, gd.device)
+            rc = _lib.load().accbpg_burg_simplex_div_prox(_ptr(yd), _ptr(gd), float(L), float(self.eps), n,
+                                                          _ptr(out), _ptr(ws), info, _stream())
+        _lib.check(rc, "accbpg_burg_simplex_div_prox", "Either y or L is not positive.")
+        self.last_info = (info[0], info[1])
+        return from_dev(out, was_np)
+
+    def prox_map(self, g, L):
+        assert L > 0, "BergEntropySimplex prox_map only takes positive L."
+        return self._prox(None, g, L)
+
+    def div_prox_map(self, y, g, L):
+        assert y.shape == g.shape, "Vectors y and g are of different sizes."
+        assert L > 0, "Either y or L is not positive."
+        return self._prox(y, g, L)
+
+
+# ------------------------------------------------------------------ vector helpers for the solver loops
+def vec_axpby(a, x, b, z):
+    """a*x + b*z with NumPy's rounding (two products, one sum)."""
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().accbpg_vec_axpby(float(a), _ptr(x), float(b), _ptr(z), x.numel(), _ptr(out), _stream())
+    _lib.check(rc, "accbpg_vec_axpby")
+    return out
+
+
+def vec_dot_diff(g, x, y):
+    """<g, x - y>  (np.dot(g, x1-x), algorithms.py:53)."""
+    out = C.c_double(0.0)
+    with torch.cuda.device(x.device):
+        ws = _Workspace.get(x.numel(), x.device)
+        rc = _lib.load().accbpg_vec_dot_diff(_ptr(g), _ptr(x), _ptr(y), x.numel(), C.byref(out), _ptr(ws), _stream())
+    _lib.check(rc, "accbpg_vec_dot_diff")
+    return out.value
+
+
+def ls_terms(g, x, y, z=None, z1=None):
+    """(<g,x-y>, D(x,y), D(z,z1)) in one launch and one readback."""
+    out = (C.c_double * 3)(0.0, 0.0, 0.0)
+    with torch.cuda.device(x.device):
+        ws = _Workspace.get(x.numel(), x.device)
+        rc = _lib.load().accbpg_ls_terms(_ptr(g), _ptr(x), _ptr(y), _ptr(z), _ptr(z1), x.numel(), out, _ptr(ws),
+                                         _stream())
+    _lib.check(rc, "accbpg_ls_terms", "Entries of x or y not positive.")
+    return out[0], out[1], out[2]
+
+
+def vec_min_sum(x):
+    out = (C.c_double * 2)(0.0, 0.0)
+    with torch.cuda.device(x.device):
+        ws = _Workspace.get(x.numel(), x.device)
+        rc = _lib.load().accbpg_vec_min_sum(_ptr(x), x.numel(), out, _ptr(ws), _stream())
+    _lib.check(rc, "accbpg_vec_min_sum")
+    return out[0], out[1]

@@ -1,0 +1,227 @@
+"""bench.py -- D-optimal design iterations/second on MI355X (BASELINE.json metric).
+
+A "step" is one outer iteration of the solver over one resident instance.  Default workload
+(N=1) is BASELINE config 2: D_opt_design(2048, 32768), ABPG_gain(gamma=2), fp64.  With --gpus N
+every rank owns an independent instance of the same shape (seeds 1..N) -- instances shard with
+no data-path collective ("scaling": "weak"); the whole-job value is N ranks' iterations over
+the max-over-ranks time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload abpg_gain|abpg|bpg|fw|fw_away]
+                    [--m 2048 --n 32768] [--no-cpu-baseline]
+
+Prints ONE JSON line on rank 0 (contract in the task description), including
+  roofline     -- dominant kernel (Gram stream-K, fp64 MFMA bound; FW workloads: the V pass, HBM bound)
+  cpu_baseline -- the NumPy oracle timed on this box's host cores on a bounded sample (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X vendor figure (fp64 matrix); confirmed on the box by accbpg_mfma_f64_peak
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="abpg_gain", choices=["abpg_gain", "abpg", "bpg", "fw", "fw_away"])
+    ap.add_argument("--m", type=int, default=2048)
+    ap.add_argument("--n", type=int, default=32768)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=1)
+    return ap.parse_args()
+
+
+def make_instance(m, n, seed, device):
+    """np.random.seed(s); randn(m,n) as accbpg/applications.py:47-49, resident in HBM."""
+    import torch
+    np.random.seed(seed)
+    V = np.random.randn(m, n)
+    return torch.from_numpy(V).to(device)
+
+
+class FWStepper:
+    """Frank-Wolfe loops as step generators over the same entry points D_opt_FW* use."""
+
+    def __init__(self, acc, f, x0, away, maxitrs):
+        from accbpg_and_fw_amd.D_opt_alg import _FWState
+        self.st = _FWState(f, x0)
+        self.away = away
+        self.m = f.m
+
+    def step(self):
+        st, m = self.st, self.m
+        pr = st.probe(away=1 if self.away else 0, refresh_logdet=1 if self.away else 0)
+        w_i, w_j = pr.w_i, pr.w_j
+        eps_pos, eps_neg = w_i / m - 1, 1 - w_j / m
+        if (not self.away) or eps_pos >= eps_neg:
+            t = (w_i / m - 1) / (w_i - 1)
+            coef = t / (1 - t + t * w_i) if self.away else t / (1 + t * (w_i - 1))
+            st.update(pr.i, 1 - t, t, -coef, 1 - t)
+        else:
+            t = min((1 - w_j / m) / (w_j - 1), pr.x_j / (1 - pr.x_j))
+            coef = t / (1 + t - t * w_j)
+            st.update(pr.j, 1 + t, -t, coef, 1 + t)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    import accbpg_and_fw_amd as acc
+    from accbpg_and_fw_amd import algorithms as alg
+
+    m, n = args.m, args.n
+    V = make_instance(m, n, 1 + rank, device)
+    f = acc.DOptimalObj(V)
+    h = acc.BurgEntropySimplex()
+    x0 = torch.full((n,), 1.0 / n, dtype=torch.float64, device=device)
+    total = args.warmup + args.steps
+
+    if args.workload == "abpg_gain":
+        gen = alg.ABPG_gain_steps(f, h, 1.0, x0, 2, total + 1, verbose=False)
+        step = lambda: next(gen)
+    elif args.workload == "abpg":
+        gen = alg.ABPG_steps(f, h, 1.0, x0, 2, total + 1, verbose=False)
+        step = lambda: next(gen)
+    elif args.workload == "bpg":
+        gen = alg.BPG_steps(f, h, 1.0, x0, total + 1, verbose=False)
+        step = lambda: next(gen)
+    else:
+        fw = FWStepper(acc, f, x0, args.workload == "fw_away", total + 1)
+        step = fw.step
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    f.profile(True)
+    calls0 = dict(f.calls)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = f.profile_read()
+    f.profile(False)
+    calls = {k: f.calls[k] - calls0[k] for k in calls0}
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tmax = float(tmax.item())
+
+    if rank == 0:
+        value = world * args.steps / tmax
+        out = {
+            "metric": "D-opt iters/sec (m=%d,n=%d)" % (m, n),
+            "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "D_opt_design(%d,%d) %s%s fp64, one independent instance per GPU"
+                                   % (m, n, args.workload, " gamma=2" if "bpg" in args.workload and args.workload != "bpg" else ""),
+                       "instances": world, "seeds": "1..%d" % world,
+                       "oracle_calls_per_step": {k: v / args.steps for k, v in calls.items()}},
+        }
+        gram_ms, gram_cnt = prof["gram"]
+        grad_ms, grad_cnt = prof["grad"]
+        kern = {k: {"ms_total": v[0], "launches": v[1], "ms_avg": (v[0] / v[1] if v[1] else None)}
+                for k, v in prof.items()}
+        out["kernels"] = kern
+        if args.workload in ("abpg_gain", "abpg", "bpg") and gram_cnt:
+            # dominant kernel: Gram stream-K.  Algorithmic flops per launch = m^2 * n (SURVEY 8(d):
+            # the SYRK share of 2 m^2 n + m^3/3 + 2 m n).
+            flops = float(m) * m * n
+            achieved = flops / (gram_ms / gram_cnt * 1e-3) * 1e-12
+            out["roofline"] = {"bound": "mfma", "kernel": "gram_streamk_kernel", "achieved": achieved,
+                               "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                               "avg_launch_ms": gram_ms / gram_cnt, "launches": gram_cnt}
+            if grad_cnt:
+                ga = flops / (grad_ms / grad_cnt * 1e-3) * 1e-12
+                out["roofline_grad_kernel"] = {"bound": "mfma", "kernel": "colnorm_kernel", "achieved": ga,
+                                               "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                               "frac": ga / PEAK_FP64_MFMA_TFLOPS,
+                                               "avg_launch_ms": grad_ms / grad_cnt, "launches": grad_cnt}
+        else:
+            # Frank-Wolfe step: HBM bound, algorithmic bytes 8 m n + 24 m^2 + 48 n per step
+            bytes_step = 8.0 * m * n + 24.0 * m * m + 48.0 * n
+            achieved = bytes_step / (tmax / args.steps) * 1e-9
+            out["roofline"] = {"bound": "hbm", "kernel": "fw step (whole step, host-timed)", "achieved": achieved,
+                               "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                               "traffic": None}
+        # measured fp64 MFMA peak on this device
+        import ctypes as C
+        from accbpg_and_fw_amd import _lib
+        tf = C.c_double(0.0)
+        _lib.load().accbpg_mfma_f64_peak(20000, C.byref(tf), None)
+        out["mfma_f64_peak_measured_tflops"] = tf.value
+
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, m, n)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, m, n):
+    """The NumPy oracle (kind "port") on this box's host cores, bounded sample."""
+    from oracle import np_oracle as O
+    np.random.seed(1)
+    V = np.random.randn(m, n)
+    fo, ho = O.DOptOracle(V), O.BurgSimplexOracle()
+    x0 = np.ones(n) / n
+    iters = max(1, args.cpu_iters)
+    t0 = time.perf_counter()
+    if args.workload == "abpg_gain":
+        O.ABPG_gain(fo, ho, 1.0, x0, 2, iters)
+    elif args.workload == "abpg":
+        O.ABPG(fo, ho, 1.0, x0, 2, iters)
+    elif args.workload == "bpg":
+        O.BPG(fo, ho, 1.0, x0, iters)
+    elif args.workload == "fw":
+        iters = max(iters, 3)
+        O.D_opt_FW(V, x0, 1e-8, iters)
+    else:
+        iters = max(iters, 3)
+        O.D_opt_FW_away(V, x0, 1e-8, iters)
+    dt = time.perf_counter() - t0
+    try:
+        import threadpoolctl
+        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count()
+    return {"value": iters / dt, "unit": "iterations/s", "cores": threads, "kind": "port",
+            "sample": "%d outer iteration(s) of the NumPy oracle %s at (%d,%d), %.1f s wall%s" %
+                      (iters, args.workload, m, n, dt,
+                       " (includes the one-off O(m^2 n) setup)" if args.workload.startswith("fw") else ""),
+            "numpy": np.__version__, "os_cpu_count": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

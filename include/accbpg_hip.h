@@ -1,0 +1,166 @@
+/*
+ * accbpg_hip.h -- C-ABI of libaccbpg_hip.so: the MI355X (gfx950) implementation of the
+ * per-iteration hot path of the accbpg package for D-optimal experiment design.
+ *
+ * The reference (DredderGun/accbpg_and_fw) is pure Python/NumPy and has no FFI of its own.
+ * The seam this library sits behind is the duck-typed f/h object protocol its solver loops
+ * call; each entry point below names the reference method whose
+ * arithmetic it replaces.  All citations are relative to the reference tree.
+ *
+ * Conventions
+ *   - every pointer named *_dev is a raw device pointer (e.g. torch.Tensor.data_ptr()),
+ *     fp64, contiguous unless a leading dimension is given;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     0 / NULL means the default stream;
+ *   - *_host outputs are plain host pointers; a call that has host outputs synchronises the
+ *     stream before it returns, so the values are valid on return;
+ *   - no entry point allocates memory the caller must free, none throws across the ABI;
+ *   - return value: ACCBPG_OK, or an ACCBPG_ERR_* code that the Python shim maps to the
+ *     exception type the reference raises in the same situation.
+ *   - one handle per host thread; handles are bound to the device current at creation.
+ */
+#ifndef ACCBPG_HIP_H
+#define ACCBPG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACCBPG_OK            0
+#define ACCBPG_ERR_ASSERT    1   /* precondition violated -> AssertionError (functions.py:44-45,251-252,269-270,340) */
+#define ACCBPG_ERR_NOT_PD    2   /* Gram matrix not positive definite -> ValueError (functions.py:48-50) */
+#define ACCBPG_ERR_HIP       3   /* HIP runtime failure -> RuntimeError; see accbpg_last_error() */
+#define ACCBPG_ERR_ARG       4   /* malformed call (null pointer, bad size) -> ValueError */
+
+typedef struct accbpg_dopt accbpg_dopt;   /* opaque D-optimal objective handle */
+
+int         accbpg_abi_version(void);
+const char* accbpg_last_error(void);
+
+/* ---- D-optimal objective: replaces DOptimalObj (accbpg/functions.py:27-59) ------------ */
+
+/* Borrow V (m x n, row-major, leading dimension ldv >= n; the reference's `self.H`,
+ * functions.py:32).  V must outlive the handle.  The handle owns all workspace
+ * (Gram matrix, Cholesky factor, inverse factor, stream-K slabs, pinned scalars). */
+int accbpg_dopt_create(const double* V_dev, int64_t m, int64_t n, int64_t ldv,
+                       void* stream, accbpg_dopt** out);
+int accbpg_dopt_destroy(accbpg_dopt* h);
+int accbpg_dopt_set_stream(accbpg_dopt* h, void* stream);
+
+/* func_grad(x, flag) of functions.py:43-59.  flag 0: value only (f_host), 1: gradient only
+ * (g_dev), 2: both.  f = -log det(V diag(x) V^T), g_i = -v_i^T (V diag(x) V^T)^-1 v_i.
+ * Returns ACCBPG_ERR_ASSERT if min(x) < 0 (functions.py:45), ACCBPG_ERR_NOT_PD if the
+ * Cholesky factorisation meets a non-positive pivot (the reference tests slogdet sign <= 0,
+ * functions.py:48-50). */
+int accbpg_dopt_func_grad(accbpg_dopt* h, const double* x_dev, int flag,
+                          double* f_host, double* g_dev);
+
+/* The same computation in three stages, for design-point sharding across GPUs
+ * (SURVEY.md 8(e).2): each rank forms its local Gram contribution, the caller all-reduces
+ * gram_dev (m*m doubles, lower triangle significant) over RCCL, every rank factors it and
+ * evaluates the gradient slice of its own columns.
+ *   gram  : gram_dev <- lower(V diag(x) V^T) of this handle's columns      (functions.py:46)
+ *   factor: in-place Cholesky of gram_dev into the handle; f_host <- -logdet (functions.py:48-51)
+ *   grad  : g_dev[i] <- -|| L^-1 v_i ||^2 for this handle's columns          (functions.py:57-58) */
+int accbpg_dopt_gram(accbpg_dopt* h, const double* x_dev, double* gram_dev);
+int accbpg_dopt_factor(accbpg_dopt* h, const double* gram_dev, double* f_host);
+int accbpg_dopt_grad(accbpg_dopt* h, double* g_dev);
+
+/* ---- Burg entropy on the simplex: replaces BurgEntropy / BurgEntropySimplex ------------
+ * (accbpg/functions.py:238-271, 326-356).  `ws_dev` is caller-provided scratch of at least
+ * accbpg_vec_workspace_doubles(n) doubles. */
+int64_t accbpg_vec_workspace_doubles(int64_t n);
+
+/* x_out <- argmin_{x in simplex} <g,x> + L*D_h(x,y)  = prox_map(g + L/y, L)
+ * (functions.py:264-271 then 336-356): same start c = -min(gg)+1, same bisection, same
+ * Newton recurrence, stall test and |phi| <= eps stopping rule; result not renormalised.
+ * y_dev == NULL selects plain prox_map(g, L) (functions.py:336).  info_host (optional,
+ * 2 ints) receives {bisection steps, Newton steps}.  ACCBPG_ERR_ASSERT if L <= 0 or
+ * min(y) <= 0. */
+int accbpg_burg_simplex_div_prox(const double* y_dev, const double* g_dev, double L, double eps,
+                                 int64_t n, double* x_out_dev, double* ws_dev,
+                                 int* info_host, void* stream);
+
+/* out_host[0] <- D_h(x,y) = sum_i (x_i/y_i - log(x_i/y_i) - 1)   (functions.py:250-253).
+ * ACCBPG_ERR_ASSERT if min(x) <= 0 or min(y) <= 0. */
+int accbpg_burg_divergence(const double* x_dev, const double* y_dev, int64_t n,
+                           double* out_host, double* ws_dev, void* stream);
+
+/* Line-search terms in one readback: out_host = { <g, x - y>, D_h(x,y), D_h(z,z1) }
+ * (algorithms.py:53, 153-154, 377-378, 387).  Any of (g), (z,z1) may be NULL to skip. */
+int accbpg_ls_terms(const double* g_dev, const double* x_dev, const double* y_dev,
+                    const double* z_dev, const double* z1_dev, int64_t n,
+                    double* out_host, double* ws_dev, void* stream);
+
+/* out <- a*x + b*z elementwise, rounded as NumPy rounds (1-theta)*x + theta*z
+ * (algorithms.py:147,150,369,374): two products, one sum, no fused multiply-add. */
+int accbpg_vec_axpby(double a, const double* x_dev, double b, const double* z_dev, int64_t n,
+                     double* out_dev, void* stream);
+
+/* out_host[0] <- <g, x - y>   (algorithms.py:53,168,387,406) */
+int accbpg_vec_dot_diff(const double* g_dev, const double* x_dev, const double* y_dev, int64_t n,
+                        double* out_host, double* ws_dev, void* stream);
+
+/* out_host = { min(x), sum(x) } -- precondition checks and diagnostics. */
+int accbpg_vec_min_sum(const double* x_dev, int64_t n, double* out_host, double* ws_dev, void* stream);
+
+/* ---- Frank-Wolfe / Wolfe-Atwood state: replaces the bodies of D_opt_FW and --------------
+ * D_opt_FW_away (accbpg/D_opt_alg.py:9-88, 91-185).  State (x, inverse H = (V X V^T)^-1,
+ * w_i = v_i^T H v_i) lives in the handle. */
+
+typedef struct accbpg_fw_probe {
+    int64_t i;         /* argmax_i w_i                         (D_opt_alg.py:59,145)            */
+    int64_t j;         /* away index                           (D_opt_alg.py:60-61 / 146-147)   */
+    double  w_i;       /* w[i]                                                                */
+    double  w_j;       /* w[j] (FW: min of w over x > 0)                                       */
+    double  x_j;       /* x[j]                                                                */
+    double  logdet_H;  /* log det of the maintained inverse H  (D_opt_alg.py:136)              */
+} accbpg_fw_probe;
+
+/* x <- x0; H <- (V diag(x0) V^T)^-1; w <- diag(V^T H V)   (D_opt_alg.py:39-45 / 123-129).
+ * logdet_gram_host <- log det(V diag(x0) V^T). */
+int accbpg_fw_init(accbpg_dopt* h, const double* x0_dev, double* logdet_gram_host);
+
+/* Reduction pass over w, x: fills *probe_host.  away = 0: j = argmin of w over {x > 0}
+ * (D_opt_alg.py:60-61); away = 1: j = argmin of (w - w_i) * [x > 1e-8], first index on ties
+ * (D_opt_alg.py:146-147).  refresh_logdet != 0 also refactors H for logdet_H (D_opt_alg.py:136). */
+int accbpg_fw_probe_step(accbpg_dopt* h, int away, int refresh_logdet, accbpg_fw_probe* probe_host);
+
+/* One rank-one update with pivot column p (i for a Frank-Wolfe step, j for an away step):
+ *   x <- x*xscale; x[p] += xadd; Hv = H V[:,p];
+ *   H <- (H + hcoef * Hv Hv^T) * hscale_inv ...  written exactly as
+ *   H <- (H + hcoef*outer(Hv,Hv)) / hdiv and w <- (w + hcoef*(Hv^T V)^2) / hdiv
+ * with the scalars computed by the caller as the reference writes them
+ * (D_opt_alg.py:75-82, 163-170, 172-179; hcoef carries its sign). */
+int accbpg_fw_update(accbpg_dopt* h, int64_t p, double xscale, double xadd, double hcoef, double hdiv);
+
+/* Copy state out (device to device): x (n), w (n), H (m*m, row-major).  NULL skips. */
+int accbpg_fw_get_state(accbpg_dopt* h, double* x_dev, double* w_dev, double* H_dev);
+
+/* ---- diagnostics ---------------------------------------------------------------------- */
+
+/* Kernel time accounting for the roofline line of bench.py: accumulates HIP-event durations
+ * of the named kernel family on the handle's stream between reset and read.
+ * which: 0 = Gram stream-K kernel (weighted SYRK), 1 = Cholesky (all its launches), 2 = triangular
+ * inverse (all its launches), 3 = gradient kernel (triangular product + column norms), 4 = Gram
+ * fix-up kernel.  enable != 0 turns event recording on. */
+int accbpg_dopt_profile_enable(accbpg_dopt* h, int enable);
+int accbpg_dopt_profile_read(accbpg_dopt* h, int which, double* total_ms_host, int64_t* launches_host);
+int accbpg_dopt_profile_reset(accbpg_dopt* h);
+
+/* fp64 MFMA peak microbenchmark: runs `iters` dependent-free v_mfma_f64_16x16x4_f64 per wave on
+ * every CU and reports achieved TFLOP/s (used to confirm the roofline constant on the box). */
+int accbpg_mfma_f64_peak(int iters, double* tflops_host, void* stream);
+
+/* Unit-test hook: C (MxN) <- alpha * A (MxK, row-major) * op(B) + beta*C on the MFMA engine.
+ * b_kmajor != 0: B is K x N row-major; else B is N x K row-major (A * B^T). */
+int accbpg_test_gemm(const double* A_dev, int64_t lda, const double* B_dev, int64_t ldb,
+                     double* C_dev, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                     int b_kmajor, double alpha, double beta, int config, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACCBPG_HIP_H */

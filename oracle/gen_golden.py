@@ -1,0 +1,187 @@
+"""Generate tests/golden/*.npz by running the REAL reference in the build container.
+
+TEST INFRASTRUCTURE ONLY.  Runs only where /root/reference exists (never on
+the GPU box).  Nothing from the reference is copied: the reference package is
+imported read-only (bytecode writing disabled), called on seeded inputs, and
+only inputs/outputs (numbers) are written out.  ``V`` for the Gaussian
+instances is never stored; tests regenerate it with the same legacy NumPy RNG
+call the factory uses (accbpg/applications.py:47-49).
+
+Usage:
+    python oracle/gen_golden.py            # small fixtures (about a minute)
+    python oracle/gen_golden.py --medium   # + (256,4096) 1000-iteration traces
+    python oracle/gen_golden.py --large    # + (2048,32768) per-call + short trajectory (tens of minutes)
+
+cvxpy and jax are not installed here and are imported at module level by the
+reference (functions.py:4-6) although nothing on this path uses them, so empty
+stand-in modules are registered for the import to succeed.
+"""
+import argparse
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def load_reference():
+    for name in ["cvxpy", "jax", "jax.numpy", "jax.scipy", "jax.scipy.linalg"]:
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["jax"].numpy = sys.modules["jax.numpy"]
+    sys.modules["jax"].scipy = sys.modules["jax.scipy"]
+    sys.modules["jax"].jit = lambda f=None, **k: f
+    sys.modules["jax.scipy"].linalg = sys.modules["jax.scipy.linalg"]
+    sys.modules["jax.scipy.linalg"].cholesky = None
+    import matplotlib
+    matplotlib.use("Agg")
+    sys.path.insert(0, REF)
+    import accbpg
+    return accbpg
+
+
+def save(name, **arrays):
+    import numpy as np
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote", path, {k: getattr(v, "shape", None) for k, v in arrays.items()})
+
+
+def percall(accbpg, tag, m, n, seed):
+    """func_grad / prox / divergence input-output pairs at a non-trivial point."""
+    import numpy as np
+    f, h, L, x0 = accbpg.D_opt_design(m, n, randseed=seed)
+    rng = np.random.RandomState(1000 + seed)
+    x = rng.rand(n) + 0.05
+    x /= x.sum()
+    fx, g = f.func_grad(x, 2)
+    f0, g0 = f.func_grad(x0, 2)
+    y = rng.rand(n) + 0.05
+    y /= y.sum()
+    out = {"m": m, "n": n, "seed": seed, "x": x, "f": fx, "g": g, "f0": f0, "g0": g0, "y": y}
+    for idx, Lc in enumerate([1.0, 0.37, 5.0]):
+        out["prox_L%d" % idx] = Lc
+        out["prox_x%d" % idx] = h.div_prox_map(y, g, Lc)
+    out["prox_raw"] = h.prox_map(g - g.min() + 0.5, 2.0)
+    out["div_xy"] = h.divergence(x, y)
+    out["div_yx"] = h.divergence(y, x)
+    save("percall_" + tag, **out)
+
+
+def solver_traces(accbpg, tag, m, n, seed, iters):
+    import numpy as np
+    f, h, L, x0 = accbpg.D_opt_design(m, n, randseed=seed)
+    out = {"m": m, "n": n, "seed": seed, "iters": iters}
+    x, F, Ls, T = accbpg.BPG(f, h, L, x0, maxitrs=iters, linesearch=False, verbose=False)
+    out.update(bpg_x=x, bpg_F=F, bpg_Ls=Ls)
+    x, F, Ls, T = accbpg.BPG(f, h, L, x0, maxitrs=iters, linesearch=True, ls_ratio=1.5, verbose=False)
+    out.update(bpgls_x=x, bpgls_F=F, bpgls_Ls=Ls)
+    x, F, G, T = accbpg.ABPG(f, h, L, x0, gamma=2, maxitrs=iters, theta_eq=False, verbose=False)
+    out.update(abpg_x=x, abpg_F=F, abpg_G=G)
+    x, F, G, T = accbpg.ABPG(f, h, L, x0, gamma=2, maxitrs=iters, theta_eq=True, restart=True,
+                             restart_rule='g', verbose=False)
+    out.update(abpgrs_x=x, abpgrs_F=F, abpgrs_G=G)
+    x, F, Gain, Gdiv, Gavg, T = accbpg.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=iters, G0=0.1,
+                                                  ls_inc=1.5, ls_dec=1.5, restart=False, verbose=False)
+    out.update(gain_x=x, gain_F=F, gain_Gain=Gain, gain_Gdiv=Gdiv, gain_Gavg=Gavg)
+    x, F, Gain, Gdiv, Gavg, T = accbpg.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=iters, verbose=False)
+    out.update(gaindef_x=x, gaindef_F=F, gaindef_Gain=Gain, gaindef_Gdiv=Gdiv, gaindef_Gavg=Gavg)
+    x, F, Gain, Gdiv, Gavg, T = accbpg.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=iters, G0=0.1,
+                                                  theta_eq=False, checkdiv=True, restart=True,
+                                                  restart_rule='f', verbose=False)
+    out.update(gainrs_x=x, gainrs_F=F, gainrs_Gain=Gain, gainrs_Gdiv=Gdiv, gainrs_Gavg=Gavg)
+    save("traces_" + tag, **out)
+
+
+def fw_traces(accbpg, tag, m, n, seed, iters, eps=1e-8):
+    import numpy as np
+    f, h, L, x0 = accbpg.D_opt_design(m, n, randseed=seed)
+    V = f.H
+    out = {"m": m, "n": n, "seed": seed, "iters": iters, "eps": eps}
+    x, F, SP, SN, T = accbpg.D_opt_FW(V, x0, eps, iters, verbose=False)
+    out.update(fw_x=x, fw_F=F, fw_SP=SP, fw_SN=SN)
+    x, F, SP, SN, T = accbpg.D_opt_FW_away(V, x0, eps, iters, verbose=False)
+    out.update(away_x=x, away_F=F, away_SP=SP, away_SN=SN)
+    save("fw_" + tag, **out)
+
+
+def housing(accbpg):
+    """RNG-free instance: the LIBSVM housing file (13 x 506 after transpose),
+    ipynb/ex_Dopt_LIBSVM.ipynb.  The parsed matrix is stored as fixture data."""
+    import numpy as np
+    path = os.path.join(REF, "parameters_free_fw", "data", "housing.txt")
+    f, h, L, x0 = accbpg.D_opt_libsvm(path)
+    V = np.ascontiguousarray(f.H)
+    out = {"V": V}
+    x, F, Ls, T = accbpg.BPG(f, h, L, x0, maxitrs=1001, linesearch=False, verbose=False)
+    out.update(bpg_x=x, bpg_F=F)
+    x, F, G, T = accbpg.ABPG(f, h, L, x0, gamma=2, maxitrs=1001, theta_eq=False, verbose=False)
+    out.update(abpg_x=x, abpg_F=F, abpg_G=G)
+    x, F, Gain, Gdiv, Gavg, T = accbpg.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=1001, G0=0.1,
+                                                  ls_inc=1.5, ls_dec=1.5, verbose=False)
+    out.update(gain_x=x, gain_F=F, gain_Gain=Gain, gain_Gdiv=Gdiv, gain_Gavg=Gavg)
+    xs, F, SP, SN, T = accbpg.D_opt_FW_away(V, x0, 1e-8, 3000, verbose=False)
+    out.update(away_x=xs, away_F=F, away_SP=SP, away_SN=SN)
+    save("housing", **out)
+
+
+def large(accbpg, m=2048, n=32768, seed=10, iters=12):
+    """Config-2 size: per-call values and a short ABPG_gain trajectory."""
+    import numpy as np
+    import time
+    f, h, L, x0 = accbpg.D_opt_design(m, n, randseed=seed)
+    t = time.time()
+    f0, g0 = f.func_grad(x0, 2)
+    print("func_grad at x0: %.1f s" % (time.time() - t), flush=True)
+    rng = np.random.RandomState(77)
+    x = rng.rand(n) + 0.05
+    x /= x.sum()
+    fx, g = f.func_grad(x, 2)
+    z = h.div_prox_map(x, g, 1.0)
+    out = {"m": m, "n": n, "seed": seed, "iters": iters, "f0": f0, "g0": g0,
+           "x": x, "f": fx, "g": g, "prox": z, "div": h.divergence(z, x)}
+    save("large_percall", **out)
+    t = time.time()
+    xs, F, Gain, Gdiv, Gavg, T = accbpg.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=iters, verbose=True)
+    print("ABPG_gain %d its: %.1f s" % (iters, time.time() - t), flush=True)
+    save("large_gain", m=m, n=n, seed=seed, iters=iters, x=xs, F=F, Gain=Gain, Gdiv=Gdiv,
+         Gavg=Gavg, ref_seconds=T[-1])
+    V = f.H
+    t = time.time()
+    xf, F, SP, SN, T = accbpg.D_opt_FW(V, x0, 1e-8, 40, verbose=False)
+    xa, Fa, SPa, SNa, Ta = accbpg.D_opt_FW_away(V, x0, 1e-8, 40, verbose=False)
+    print("FW 40 its x2: %.1f s" % (time.time() - t), flush=True)
+    save("large_fw", m=m, n=n, seed=seed, fw_x=xf, fw_F=F, fw_SP=SP, fw_SN=SN,
+         away_x=xa, away_F=Fa, away_SP=SPa, away_SN=SNa)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--medium", action="store_true")
+    ap.add_argument("--large", action="store_true")
+    ap.add_argument("--only-large", action="store_true")
+    args = ap.parse_args()
+    accbpg = load_reference()
+    if not args.only_large:
+        percall(accbpg, "80x200", 80, 200, 10)
+        percall(accbpg, "128x1024", 128, 1024, 3)
+        percall(accbpg, "200x2000", 200, 2000, 7)
+        solver_traces(accbpg, "80x200", 80, 200, 10, 1000)
+        solver_traces(accbpg, "80x120", 80, 120, 10, 300)
+        fw_traces(accbpg, "30x1000", 30, 1000, 5, 6000)
+        fw_traces(accbpg, "64x512", 64, 512, 2, 3000)
+        housing(accbpg)
+    if args.medium:
+        percall(accbpg, "512x8192", 512, 8192, 1)
+        solver_traces(accbpg, "256x4096", 256, 4096, 10, 1000)
+        fw_traces(accbpg, "256x4096", 256, 4096, 10, 2000)
+    if args.large or args.only_large:
+        large(accbpg)
+
+
+if __name__ == "__main__":
+    main()

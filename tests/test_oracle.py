@@ -1,0 +1,126 @@
+"""CPU tests: the NumPy oracle against golden vectors produced by the real
+reference (oracle/gen_golden.py) and against the notebook rows that the
+reference stores as its only regression data."""
+import numpy as np
+import pytest
+
+from conftest import golden, gaussian_design
+from oracle import np_oracle as O
+
+
+@pytest.mark.parametrize("tag", ["80x200", "128x1024", "200x2000"])
+def test_percall_matches_reference(tag):
+    gd = golden("percall_" + tag)
+    m, n, seed = int(gd["m"]), int(gd["n"]), int(gd["seed"])
+    f, h, L, x0 = O.D_opt_design(m, n, randseed=seed)
+    fx, g = f.func_grad(gd["x"], 2)
+    assert fx == pytest.approx(float(gd["f"]), rel=0, abs=1e-12)
+    np.testing.assert_allclose(g, gd["g"], rtol=1e-13, atol=0)
+    f0, g0 = f.func_grad(x0, 2)
+    assert f0 == pytest.approx(float(gd["f0"]), rel=0, abs=1e-12)
+    np.testing.assert_allclose(g0, gd["g0"], rtol=1e-13)
+    assert f(gd["x"]) == fx
+    for idx in range(3):
+        z = h.div_prox_map(gd["y"], gd["g"], float(gd["prox_L%d" % idx]))
+        np.testing.assert_array_equal(z, gd["prox_x%d" % idx])   # same arithmetic -> bitwise
+    gg = gd["g"] - gd["g"].min() + 0.5
+    np.testing.assert_array_equal(h.prox_map(gg, 2.0), gd["prox_raw"])
+    assert h.divergence(gd["x"], gd["y"]) == float(gd["div_xy"])
+    assert h.divergence(gd["y"], gd["x"]) == float(gd["div_yx"])
+
+
+def _check(a, b, tol):
+    assert a.shape == b.shape
+    np.testing.assert_allclose(a, b, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("tag", ["80x200", "80x120"])
+def test_solver_traces_match_reference(tag):
+    gd = golden("traces_" + tag)
+    m, n, seed, iters = int(gd["m"]), int(gd["n"]), int(gd["seed"]), int(gd["iters"])
+    f, h, L, x0 = O.D_opt_design(m, n, randseed=seed)
+    tol = 1e-12
+    x, F, Ls, T = O.BPG(f, h, L, x0, maxitrs=iters, linesearch=False)
+    _check(x, gd["bpg_x"], tol); _check(F, gd["bpg_F"], tol); _check(Ls, gd["bpg_Ls"], tol)
+    x, F, Ls, T = O.BPG(f, h, L, x0, maxitrs=iters, linesearch=True, ls_ratio=1.5)
+    _check(x, gd["bpgls_x"], tol); _check(F, gd["bpgls_F"], tol); _check(Ls, gd["bpgls_Ls"], tol)
+    x, F, G, T = O.ABPG(f, h, L, x0, gamma=2, maxitrs=iters, theta_eq=False)
+    _check(x, gd["abpg_x"], tol); _check(F, gd["abpg_F"], tol); _check(G, gd["abpg_G"], 1e-9)
+    x, F, G, T = O.ABPG(f, h, L, x0, gamma=2, maxitrs=iters, theta_eq=True, restart=True, restart_rule='g')
+    _check(x, gd["abpgrs_x"], tol); _check(F, gd["abpgrs_F"], tol)
+    x, F, Gain, Gdiv, Gavg, T = O.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=iters, G0=0.1,
+                                             ls_inc=1.5, ls_dec=1.5)
+    _check(x, gd["gain_x"], tol); _check(F, gd["gain_F"], tol)
+    _check(Gain, gd["gain_Gain"], tol); _check(Gavg, gd["gain_Gavg"], tol)
+    x, F, Gain, Gdiv, Gavg, T = O.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=iters)
+    _check(x, gd["gaindef_x"], tol); _check(F, gd["gaindef_F"], tol); _check(Gain, gd["gaindef_Gain"], tol)
+    x, F, Gain, Gdiv, Gavg, T = O.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=iters, G0=0.1, theta_eq=False,
+                                             checkdiv=True, restart=True, restart_rule='f')
+    _check(x, gd["gainrs_x"], tol); _check(F, gd["gainrs_F"], tol); _check(Gain, gd["gainrs_Gain"], tol)
+
+
+@pytest.mark.parametrize("tag", ["30x1000", "64x512"])
+def test_fw_traces_match_reference(tag):
+    gd = golden("fw_" + tag)
+    m, n, seed, iters = int(gd["m"]), int(gd["n"]), int(gd["seed"]), int(gd["iters"])
+    V = gaussian_design(m, n, seed)
+    x0 = np.ones(n) / n
+    x, F, SP, SN, T = O.D_opt_FW(V, x0, float(gd["eps"]), iters)
+    _check(x, gd["fw_x"], 1e-12); _check(F, gd["fw_F"], 1e-11)
+    _check(SP, gd["fw_SP"], 1e-11); _check(SN, gd["fw_SN"], 1e-11)
+    x, F, SP, SN, T = O.D_opt_FW_away(V, x0, float(gd["eps"]), iters)
+    _check(x, gd["away_x"], 1e-12); _check(F, gd["away_F"], 1e-11)
+    _check(SP, gd["away_SP"], 1e-11); _check(SN, gd["away_SN"], 1e-11)
+
+
+def test_housing_rng_free_instance():
+    gd = golden("housing")
+    V = gd["V"]
+    assert V.shape == (13, 506)
+    n = V.shape[1]
+    f, h = O.DOptOracle(V), O.BurgSimplexOracle()
+    x0 = np.ones(n) / n
+    # F(x0) for the LIBSVM housing file, SURVEY.md 8(c) / ipynb/ex_Dopt_LIBSVM.ipynb:191
+    assert "%.3e" % f(x0) == "-4.137e+01"
+    x, F, Ls, T = O.BPG(f, h, 1.0, x0, maxitrs=1001, linesearch=False)
+    _check(F, gd["bpg_F"], 1e-11); _check(x, gd["bpg_x"], 1e-11)
+    x, F, Gain, Gdiv, Gavg, T = O.ABPG_gain(f, h, 1.0, x0, gamma=2, maxitrs=1001, G0=0.1,
+                                             ls_inc=1.5, ls_dec=1.5)
+    _check(F, gd["gain_F"], 1e-10); _check(Gain, gd["gain_Gain"], 1e-10)
+    x, F, SP, SN, T = O.D_opt_FW_away(V, x0, 1e-8, 3000)
+    _check(x, gd["away_x"], 1e-10); _check(F, gd["away_F"], 1e-9)
+
+
+def test_notebook_rows_ex_Dopt_random():
+    """Rows stored in ipynb/ex_Dopt_random.ipynb (D_opt_design(80,200,randseed=10)):
+    :73,:82 BPG no-LS; :243-244 BPG-LS; :113 ABPG gamma=2; :282-283 ABPG_gain(G0=0.1)."""
+    f, h, L, x0 = O.D_opt_design(80, 200, randseed=10)
+    x, F, Ls, T = O.BPG(f, h, L, x0, maxitrs=1000, linesearch=False)
+    assert "%.3e" % F[0] == "1.910e+01" and "%.3e" % F[900] == "1.759e+01"
+    x, F, Ls, T = O.BPG(f, h, L, x0, maxitrs=200, linesearch=True, ls_ratio=1.5)
+    assert "%.3e" % Ls[0] == "6.667e-01" or "%.3e" % Ls[0] == "8.333e-01"
+    x, F, G, T = O.ABPG(f, h, L, x0, gamma=2, maxitrs=200, theta_eq=False)
+    theta100 = 2.0 / (100 + 2.0)
+    assert "%.3e" % G[100] == "5.529e-01"
+    x, F, Gain, Gdiv, Gavg, T = O.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=200, G0=0.1,
+                                             ls_inc=1.5, ls_dec=1.5)
+    assert "%.3e" % Gain[0] == "2.488e-01" or "%.3e" % Gavg[0] == "4.988e-02"
+    f2, h2, L2, x02 = O.D_opt_design(80, 120, randseed=10)
+    assert "%.3e" % f2(x02) == "3.764e+01"
+
+
+def test_solve_theta_and_asserts():
+    t = O.solve_theta(0.5, 2.0, 1.0)
+    assert abs((1 - t) / t ** 2 - 1 / 0.25) < 1e-4
+    f, h, L, x0 = O.D_opt_design(8, 20, randseed=3)
+    with pytest.raises(AssertionError):
+        f.func_grad(-x0)
+    with pytest.raises(AssertionError):
+        f.func_grad(x0[:-1])
+    with pytest.raises(ValueError):
+        z = np.zeros(20); z[:3] = 1.0 / 3      # rank-deficient Gram matrix: slogdet sign 0
+        f.func_grad(z)
+    with pytest.raises(AssertionError):
+        h.div_prox_map(x0, x0, -1.0)
+    with pytest.raises(AssertionError):
+        h.divergence(x0, 0 * x0)
