@@ -239,97 +239,366 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_big_kernel(GemmOp op) {
 }
 
 // =========================================================================================
-// Cholesky, right-looking, block NB = 64.
+// Cholesky, right-looking, block NB = 64, ONE launch per block column.
+//
+// Launch `kprev` (= -1 .. T-2) receives block column kprev finished (L(:,kprev) in place) and
+//   * panel workgroups (one per block row i >= kc = kprev+1): bring the diagonal block
+//     D = A(kc,kc) - L(kc,kprev) L(kc,kprev)^T up to date (each redundantly: 64^3 MFMA work),
+//     factor it in LDS, then either write it back (i == kc, with its log-det share) or solve
+//     their own panel block  L(i,kc) = (A(i,kc) - L(i,kprev) L(kc,kprev)^T) L(kc,kc)^-T;
+//   * update workgroups: A(i,j) -= L(i,kprev) L(j,kprev)^T for the remaining tiles j > kc.
+// Everything a launch reads was written by earlier launches, so there is no hand-off between
+// workgroups inside a launch; T launches factor the matrix.
 // =========================================================================================
-constexpr int SP = NB + 1;   // LDS stride of a 64x64 block image
+constexpr int SP = NB + 1;   // LDS stride of a 64x64 block image (row reads by one lane per row)
+constexpr int SQ = NB + 2;   // LDS stride of a 64x64 MFMA operand image (ds_read_b64 conflict-free)
+constexpr int CHOL_LDS_DOUBLES = 2 * NB * SQ + 2 * NB * SP + 6 * NB;
+constexpr int CHOL_LDS_BYTES = CHOL_LDS_DOUBLES * 8;
 
-// Factor the bs x bs diagonal block at A[k0][k0] in LDS.  One barrier per column: the update of
-// step c touches columns > c only while everybody reads column c, and the finished column goes
-// to a second image.  Adds 2*sum(log L_ii) to *logdet (stream order fixes the summation order),
-// raises flags[FLAG_NOT_PD] on a non-positive (or NaN) pivot.
-__global__ __launch_bounds__(NTHREADS) void potrf_diag_kernel(double* __restrict__ A, int64_t lda, int64_t k0,
-                                                             int bs, double* __restrict__ logdet,
-                                                             int* __restrict__ flags) {
-    __shared__ double S[NB * SP];
-    __shared__ double Lo[NB * SP];
-    __shared__ double red[4];
-    const int tid = threadIdx.x;
-    double* Ab = A + k0 * lda + k0;
-    for (int e = tid; e < NB * NB; e += NTHREADS) {
-        const int r = e / NB, c = e % NB;
-        S[r * SP + c] = (r < bs && c <= r) ? Ab[(int64_t)r * lda + c] : ((r == c) ? 1.0 : 0.0);
-        Lo[r * SP + c] = 0.0;
-    }
-    const int r = tid & 63, q = tid >> 6;
-    bool bad = false;
-    for (int c = 0; c < bs; ++c) {
-        __syncthreads();
-        double d = S[c * SP + c];
-        if (!(d > 0.0)) { bad = true; d = 1.0; }
-        const double piv = sqrt(d);
-        const double rpiv = 1.0 / piv;
-        if (r >= c) {
-            const double lrc = (r == c) ? piv : S[r * SP + c] * rpiv;
-            if (q == 0) Lo[r * SP + c] = lrc;
-            if (r > c) {
-                for (int cc = c + 1 + ((q - (c + 1)) & 3); cc <= r; cc += 4)
-                    S[r * SP + cc] -= lrc * (S[cc * SP + c] * rpiv);
-            }
-        }
-    }
-    __syncthreads();
-    for (int e = tid; e < NB * NB; e += NTHREADS) {
-        const int rr = e / NB, c = e % NB;
-        if (rr < bs && c <= rr) Ab[(int64_t)rr * lda + c] = Lo[rr * SP + c];
-    }
-    // log-determinant contribution, fixed reduction tree
-    double lg = (tid < bs) ? log(Lo[tid * SP + tid]) : 0.0;
-    for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off);
-    if ((tid & 63) == 0) red[tid >> 6] = lg;
-    __syncthreads();
-    if (tid == 0) {
-        *logdet += 2.0 * (red[0] + red[1] + red[2] + red[3]);
-        if (bad) flags[FLAG_NOT_PD] = 1;
+typedef d4 acc64_t[2][2];   // 64x64 product on 4 waves (2x2), wave tile 32x32 = 2x2 MFMA fragments
+
+// acc = As * Bs^T for two 64x64 operand images (k-contiguous, stride SQ) resident in LDS
+__device__ __forceinline__ void mma64(acc64_t& acc, const double* __restrict__ As, const double* __restrict__ Bs) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lq = lane >> 4;
+    const double* ap = As + (16 * wm + lr) * SQ + lq;          // fragment i: rows 16*(2i+wm)
+    const double* bp = Bs + (32 * wn + lr) * SQ + lq;          // fragment j: cols 32*wn + 16j
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int kk = 0; kk < NB / 4; ++kk) {
+        const double a0 = ap[4 * kk], a1 = ap[32 * SQ + 4 * kk];
+        const double b0 = bp[4 * kk], b1 = bp[16 * SQ + 4 * kk];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
 }
 
-// Panel solve below the diagonal block: X * L11^T = A21, one thread per row, 64 rows per
-// workgroup; the row lives in registers, L11 is read from LDS by broadcast.
-__global__ __launch_bounds__(64) void trsm_panel_kernel(double* __restrict__ A, int64_t lda, int64_t k0, int bs,
-                                                       int64_t m) {
-    __shared__ double Ls[NB * SP];
-    __shared__ double Xs[NB * SP];
-    __shared__ double rinv[NB];
+// img[row][col] -= acc (image stride SP), guarded by (row < mr && col < mc) and optionally col <= row
+__device__ __forceinline__ void sub_acc64(double* __restrict__ img, const acc64_t& acc, int mr, int mc, bool lower) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * (2 * i + wm) + lq + 4 * r, col = 32 * wn + 16 * j + lr;
+                if (row < mr && col < mc && (!lower || col <= row)) img[row * SP + col] -= acc[i][j][r];
+            }
+}
+
+// 64x64 block of a row-major matrix -> registers (16 doubles per thread, 16-byte pieces), zero padded
+struct Blk64 {
+    d2 v[8];
+    __device__ __forceinline__ void load(const double* __restrict__ G, int64_t ld, int mr, int mc, bool vec_ok) {
+        const int tid = threadIdx.x;
+        const int c = 2 * (tid & 31), r0 = tid >> 5;           // 32 threads cover a 64-double row
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int r = r0 + 8 * p;
+            v[p] = load2_guard(G + (int64_t)r * ld + c, r < mr, c, mc, vec_ok);
+        }
+    }
+    // into an image with row stride `st`
+    __device__ __forceinline__ void to_lds(double* __restrict__ img, int st) const {
+        const int tid = threadIdx.x;
+        const int c = 2 * (tid & 31), r0 = tid >> 5;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            img[(r0 + 8 * p) * st + c] = v[p].x;
+            img[(r0 + 8 * p) * st + c + 1] = v[p].y;
+        }
+    }
+    __device__ __forceinline__ void from_lds(const double* __restrict__ img, int st) {
+        const int tid = threadIdx.x;
+        const int c = 2 * (tid & 31), r0 = tid >> 5;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            v[p].x = img[(r0 + 8 * p) * st + c];
+            v[p].y = img[(r0 + 8 * p) * st + c + 1];
+        }
+    }
+    __device__ __forceinline__ void store(double* __restrict__ G, int64_t ld, int mr, int mc, bool lower) const {
+        const int tid = threadIdx.x;
+        const int c = 2 * (tid & 31), r0 = tid >> 5;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int r = r0 + 8 * p;
+            if (r < mr) {
+                if (c < mc && (!lower || c <= r)) G[(int64_t)r * ld + c] = v[p].x;
+                if (c + 1 < mc && (!lower || c + 1 <= r)) G[(int64_t)r * ld + c + 1] = v[p].y;
+            }
+        }
+    }
+};
+
+// 1/sqrt(d) and sqrt(d) to fp64 accuracy from v_rsq_f64 plus Newton/Heron corrections (the pivot
+// chain of the factorisation is latency-bound; this is half the dependent depth of sqrt + divide).
+__device__ __forceinline__ void rsqrt_sqrt(double d, double& rp, double& piv) {
+    double y = __builtin_amdgcn_rsq(d);
+    double h = 0.5 * d;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    double sq = d * y;
+    sq = fma(fma(-sq, sq, d), 0.5 * y, sq);
+    rp = y;
+    piv = sq;
+}
+
+// quad broadcast on DPP: every lane of a quad gets lane `src`'s value, no LDS round trip
+template <int SRC>
+__device__ __forceinline__ double quad_bcast(double v) {
+    constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// Factor the 64x64 block image S (lower, identity-padded beyond bs) into Lo.
+// Thread (r = tid & 63, q = tid >> 6) keeps row r's entries of the columns 4t+q in registers; the
+// register file is rotated one place after every group of four columns, so the loop over groups is
+// a real loop (small body, stays in the instruction cache) with compile-time register indices.
+// Per column one barrier: the owner wave of column c+1 publishes it UNSCALED right after its last
+// update, the owner of its diagonal entry also publishes (1/sqrt, sqrt) of the pivot; after the
+// barrier every thread needs one multiply for l_rc and one FMA per register:
+//   a[r][cc] -= (l_rc / piv) * a[cc][c].
+// Finished columns and entries above the diagonal carry garbage that is never read back.
+__device__ __forceinline__ void potrf64_lds(const double* __restrict__ S, double* __restrict__ Lo,
+                                            double* __restrict__ colbuf /* 2 x 64 (+64 pad) */,
+                                            double* __restrict__ pvbuf /* 2 x 2 */, int* __restrict__ badflag,
+                                            int bs) {
     const int tid = threadIdx.x;
-    const double* L11 = A + k0 * lda + k0;
-    const int64_t prow0 = k0 + bs + (int64_t)blockIdx.x * NB;
-    const int nrows = (int)min((int64_t)NB, m - prow0);
-    double* P = A + prow0 * lda + k0;
-    for (int e = tid; e < NB * NB; e += 64) {
-        const int r = e / NB, c = e % NB;
-        Ls[r * SP + c] = (r < bs && c <= r) ? L11[(int64_t)r * lda + c] : ((r == c) ? 1.0 : 0.0);
-        Xs[r * SP + c] = (r < nrows && c < bs) ? P[(int64_t)r * lda + c] : 0.0;
+    const int r = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double a[NB / 4];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NB / 4; ++t) a[t] = S[r * SP + 4 * t + q];
+    if (q == 0) {
+        colbuf[r] = a[0];
+        if (r == 0) {
+            double d = a[0];
+            if (!(d > 0.0)) { *badflag = 1; d = 1.0; }
+            double rp, piv;
+            rsqrt_sqrt(d, rp, piv);
+            pvbuf[0] = rp;
+            pvbuf[1] = piv;
+        }
     }
     __syncthreads();
-    rinv[tid] = 1.0 / Ls[tid * SP + tid];
-    __syncthreads();
-    double xr[NB];
+#pragma unroll 1
+    for (int cg = 0; cg < NB / 4; ++cg) {
 #pragma unroll
-    for (int c = 0; c < NB; ++c) xr[c] = Xs[tid * SP + c];
+        for (int ci = 0; ci < 4; ++ci) {
+            const int c = 4 * cg + ci;
+            const int par = ci & 1;                               // c & 1
+            const double* col = colbuf + par * NB;
+            const double rp = pvbuf[2 * par], piv = pvbuf[2 * par + 1];
+            const double lrc = (r == c) ? piv : col[r] * rp;
+            if (q == ci) Lo[r * SP + c] = (r >= c) ? lrc : 0.0;
+            const double w = lrc * rp;
+            // column c+1 first: it heads the dependent chain of the next step.  It lives in a[0] of
+            // wave ci+1, or (ci == 3) in a[1] of wave 0.
+            const int qn = (ci + 1) & 3;
+            const int tn = (ci == 3) ? 1 : 0;
+            if (q == qn && c + 1 < NB) {
+                const double an = fma(-w, col[c + 1], a[tn]);
+                a[tn] = an;
+                colbuf[(par ^ 1) * NB + r] = an;
+                if (r == c + 1) {
+                    double d = an;
+                    if (!(d > 0.0)) { if (c + 1 < bs) *badflag = 1; d = 1.0; }
+                    double rpn, pivn;
+                    rsqrt_sqrt(d, rpn, pivn);
+                    pvbuf[2 * (par ^ 1)] = rpn;
+                    pvbuf[2 * (par ^ 1) + 1] = pivn;
+                }
+            }
+            // the other live registers (reads past column 63 hit the pad; those registers are dead)
+            const double* colq = col + 4 * cg + q;
+            double cv[NB / 4];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) {
-        double s = xr[c];
+            for (int t = 0; t < NB / 4; ++t) cv[t] = colq[4 * t];   // one batch of independent reads (pad past 63)
 #pragma unroll
-        for (int cc = 0; cc < c; ++cc) s -= xr[cc] * Ls[c * SP + cc];
-        xr[c] = s * rinv[c];
+            for (int t = 0; t < NB / 4; ++t) {
+                if (t == tn) {
+                    if (q != qn) a[t] = fma(-w, cv[t], a[t]);
+                } else {
+                    a[t] = fma(-w, cv[t], a[t]);
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int t = 0; t + 1 < NB / 4; ++t) a[t] = a[t + 1];
+        a[NB / 4 - 1] = 0.0;
     }
+}
+
+// Solve X * L^T = P for the 64 rows of Xs in place, L = Lo (64x64 lower, unit-padded), right-looking:
+// four lanes per row keep the not-yet-solved right-hand side p[4t+q] in rotating registers; each
+// step scales one entry, broadcasts it over the quad (DPP) and updates the rest:
+//   x_c = p_c / L[c][c];  p_cc -= x_c * L[cc][c].   No barrier inside.
+__device__ __forceinline__ void trsm64_lds(double* __restrict__ Xs, const double* __restrict__ Lo,
+                                           const double* __restrict__ rinv) {
+    const int tid = threadIdx.x;
+    const int row = tid >> 2, q = tid & 3;
+    double p[NB / 4];
 #pragma unroll
-    for (int c = 0; c < NB; ++c) Xs[tid * SP + c] = xr[c];
-    __syncthreads();
-    for (int e = tid; e < NB * NB; e += 64) {
-        const int r = e / NB, c = e % NB;
-        if (r < nrows && c < bs) P[(int64_t)r * lda + c] = Xs[r * SP + c];
+    for (int t = 0; t < NB / 4; ++t) p[t] = Xs[row * SP + 4 * t + q];
+#pragma unroll 1
+    for (int cg = 0; cg < NB / 4; ++cg) {
+        // rows (4cg+q+4t) of L, wrapped into 0..63 for the registers already past column 63 (dead)
+        const double* lrow[NB / 4];
+#pragma unroll
+        for (int t = 0; t < NB / 4; ++t) lrow[t] = Lo + ((4 * cg + q + 4 * t) & (NB - 1)) * SP + 4 * cg;
+        double xc[4];
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci) {
+            const int c = 4 * cg + ci;
+            double lv[NB / 4];
+#pragma unroll
+            for (int t = 0; t < NB / 4; ++t) lv[t] = lrow[t][ci];   // independent of the solve chain
+            const double mine = p[0] * rinv[c];
+            double x;
+            if (ci == 0) x = quad_bcast<0>(mine);
+            else if (ci == 1) x = quad_bcast<1>(mine);
+            else if (ci == 2) x = quad_bcast<2>(mine);
+            else x = quad_bcast<3>(mine);
+            xc[ci] = x;
+#pragma unroll
+            for (int t = 0; t < NB / 4; ++t) p[t] = fma(-x, lv[t], p[t]);
+        }
+        if (q == 0) Xs[row * SP + 4 * cg + 0] = xc[0];
+        if (q == 1) Xs[row * SP + 4 * cg + 1] = xc[1];
+        if (q == 2) Xs[row * SP + 4 * cg + 2] = xc[2];
+        if (q == 3) Xs[row * SP + 4 * cg + 3] = xc[3];
+#pragma unroll
+        for (int t = 0; t + 1 < NB / 4; ++t) p[t] = p[t + 1];
+        p[NB / 4 - 1] = 0.0;
     }
+}
+
+__global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restrict__ A, int64_t lda, int64_t m,
+                                                               int kprev, int T, double* __restrict__ logdet,
+                                                               int* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* Ak = lds;                       // 64 x SQ : L(i,kprev) operand image
+    double* Bk = Ak + NB * SQ;              // 64 x SQ : L(kc,kprev) (or L(j,kprev)) operand image
+    double* S = Bk + NB * SQ;               // 64 x SP : diagonal block image, later the panel block
+    double* Lo = S + NB * SP;               // 64 x SP (+ pad rows read by the solve): factor
+    double* rinv = Lo + NB * SP;            // NB, followed by NB of zero pad (rows 64.. of Lo reads)
+    double* colbuf = rinv + 2 * NB;         // 2 x NB + NB pad
+    double* pvbuf = colbuf + 3 * NB;        // 4 (+ flag)
+    int* badflag = reinterpret_cast<int*>(pvbuf + 8);
+    double* red = pvbuf + 16;
+    const int tid = threadIdx.x;
+    const int kc = kprev + 1;
+    const int npanel = T - kc;
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0);
+    const double* Lk = A + (int64_t)kprev * NB;     // block column kprev (unused if kprev < 0)
+    acc64_t acc;
+
+    if ((int)blockIdx.x >= npanel) {
+        // ---- update role: tile (i, j), kc < j <= i:  A(i,j) -= L(i,kprev) L(j,kprev)^T
+        const int u = blockIdx.x - npanel;
+        int ii = (int)((sqrt(8.0 * u + 1.0) - 1.0) * 0.5);
+        while ((ii + 1) * (ii + 2) / 2 <= u) ++ii;
+        while (ii * (ii + 1) / 2 > u) --ii;
+        const int jj = u - ii * (ii + 1) / 2;
+        const int i = kc + 1 + ii, j = kc + 1 + jj;
+        const int mi = (int)min((int64_t)NB, m - (int64_t)i * NB), mj = (int)min((int64_t)NB, m - (int64_t)j * NB);
+        Blk64 bi, bj, bc;
+        bi.load(Lk + (int64_t)i * NB * lda, lda, mi, NB, vec_ok);
+        bj.load(Lk + (int64_t)j * NB * lda, lda, mj, NB, vec_ok);
+        double* Cij = A + (int64_t)i * NB * lda + (int64_t)j * NB;
+        bc.load(Cij, lda, mi, mj, vec_ok);
+        bi.to_lds(Ak, SQ);
+        bj.to_lds(Bk, SQ);
+        bc.to_lds(S, SP);
+        __syncthreads();
+        mma64(acc, Ak, Bk);
+        sub_acc64(S, acc, mi, mj, i == j);
+        __syncthreads();
+        bc.from_lds(S, SP);
+        bc.store(Cij, lda, mi, mj, i == j);
+        return;
+    }
+
+    // ---- panel role: block row i of block column kc
+    const int i = kc + blockIdx.x;
+    const bool diag = (i == kc);
+    const int bs = (int)min((int64_t)NB, m - (int64_t)kc * NB);
+    const int mi = (int)min((int64_t)NB, m - (int64_t)i * NB);
+    double* Akk = A + (int64_t)kc * NB * lda + (int64_t)kc * NB;
+    double* Pik = A + (int64_t)i * NB * lda + (int64_t)kc * NB;
+    Blk64 bkk, bik, bd, bp;
+    // every global load of this workgroup is issued before anything waits
+    bd.load(Akk, lda, bs, bs, vec_ok);
+    if (kprev >= 0) bkk.load(Lk + (int64_t)kc * NB * lda, lda, bs, NB, vec_ok);
+    if (!diag) {
+        bp.load(Pik, lda, mi, bs, vec_ok);
+        if (kprev >= 0) bik.load(Lk + (int64_t)i * NB * lda, lda, mi, NB, vec_ok);
+    }
+    // diagonal image: lower part, identity padding
+    {
+        const int c = 2 * (tid & 31), r0 = tid >> 5;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int r = r0 + 8 * p;
+            const bool in = r < bs;
+            S[r * SP + c] = (in && c <= r) ? bd.v[p].x : ((r == c) ? 1.0 : 0.0);
+            S[r * SP + c + 1] = (in && c + 1 <= r && c + 1 < bs) ? bd.v[p].y : ((r == c + 1) ? 1.0 : 0.0);
+        }
+    }
+    for (int e = tid; e < 2 * NB; e += NTHREADS) rinv[e] = 0.0;
+    for (int e = tid; e < 3 * NB; e += NTHREADS) colbuf[e] = 0.0;
+    if (tid == 0) *badflag = 0;
+    acc64_t pacc;
+    if (kprev >= 0) {
+        bkk.to_lds(Bk, SQ);
+        if (!diag) bik.to_lds(Ak, SQ);
+        __syncthreads();
+        mma64(acc, Bk, Bk);                              // L(kc,kprev) L(kc,kprev)^T
+        if (!diag) mma64(pacc, Ak, Bk);                  // L(i,kprev) L(kc,kprev)^T
+        sub_acc64(S, acc, bs, bs, true);
+    }
+    potrf64_lds(S, Lo, colbuf, pvbuf, badflag, bs);      // starts and ends with a barrier
+    const bool bad = (*badflag != 0);
+    if (diag) {
+        Blk64 bl;
+        bl.from_lds(Lo, SP);
+        bl.store(Akk, lda, bs, bs, true);
+        double lg = (tid < bs) ? log(Lo[tid * SP + tid]) : 0.0;
+        for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off);
+        if ((tid & 63) == 0) red[tid >> 6] = lg;
+        __syncthreads();
+        if (tid == 0) {
+            *logdet += 2.0 * (red[0] + red[1] + red[2] + red[3]);
+            if (bad) flags[FLAG_NOT_PD] = 1;
+        }
+        return;
+    }
+    // panel block: P = A(i,kc) - L(i,kprev) L(kc,kprev)^T, then X L^T = P
+    double* Xs = S;                                      // the diagonal image is dead after the factorisation
+    bp.to_lds(Xs, SP);
+    if (tid < NB) rinv[tid] = (tid < bs) ? 1.0 / Lo[tid * SP + tid] : 0.0;
+    __syncthreads();
+    if (kprev >= 0) sub_acc64(Xs, pacc, mi, bs, false);
+    __syncthreads();
+    trsm64_lds(Xs, Lo, rinv);
+    __syncthreads();
+    bp.from_lds(Xs, SP);
+    bp.store(Pik, lda, mi, bs, false);
 }
 
 // Inverse of every 64x64 diagonal block of L: thread j solves L11 w = e_j (column j of the
@@ -375,7 +644,8 @@ __global__ void zero_scalars_kernel(double* dscal, int* dflag) {
 
 __global__ void set_op_kernel(GemmOp* slot, GemmOp op) { *slot = op; }
 
-// fp64 MFMA peak: every wave issues `iters` x 8 independent-accumulator MFMAs
+// fp64 MFMA peak: every wave issues `iters` x 8 independent-accumulator MFMAs (inline asm keeps the
+// accumulators where they are; the builtin form made hipcc shuttle them through the AGPR file).
 __global__ __launch_bounds__(NTHREADS, 1) void mfma_peak_kernel(int iters, double* sink) {
     d4 acc[8];
 #pragma unroll
@@ -383,8 +653,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void mfma_peak_kernel(int iters, doubl
     double a = 1.0 + threadIdx.x * 1e-3, b = 0.5 - threadIdx.x * 1e-3;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < 8; ++i)
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     double s = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
@@ -500,6 +772,7 @@ int build_plans(accbpg_dopt* h) {
     ACC_TRY(set_lds(colnorm_kernel<TileSmall<true, false>>, TileSmall<true>::LDS_BYTES));
     ACC_TRY(set_lds(gemm_ops_kernel<TileSmall<true>>, TileSmall<true>::LDS_BYTES));
     ACC_TRY(set_lds(gemm_ops_kernel<TileSmall<false>>, TileSmall<false>::LDS_BYTES));
+    ACC_TRY(set_lds(chol_step_kernel, CHOL_LDS_BYTES));
     ACC_TRY(set_lds(gemm_big_kernel<TileBig<true>>, TileBig<true>::LDS_BYTES));
     ACC_TRY(set_lds(gemm_big_kernel<TileBig<false>>, TileBig<false>::LDS_BYTES));
     return ACCBPG_OK;
@@ -544,26 +817,19 @@ int launch_gemm_ops(const GemmOp* ops_dev, int nops, int maxM, int maxN, bool b_
 }
 
 // In-place Cholesky of the lower triangle of A (m x m, ld m).  Resets and fills dscal[0] (log det)
-// and dflag[FLAG_NOT_PD].
+// and dflag[FLAG_NOT_PD].  T = ceil(m/64) launches.
 int launch_cholesky(accbpg_dopt* h, double* A) {
     const int64_t m = h->m;
     const int T = (int)((m + NB - 1) / NB);
     prof_begin(h, PROF_CHOL);
     zero_scalars_kernel<<<1, 64, 0, h->stream>>>(h->dscal, h->dflag);
-    for (int k = 0; k < T; ++k) {
-        const int64_t k0 = (int64_t)k * NB;
-        const int bs = (int)std::min<int64_t>(NB, m - k0);
-        potrf_diag_kernel<<<1, NTHREADS, 0, h->stream>>>(A, m, k0, bs, h->dscal, h->dflag);
-        const int64_t rem = m - k0 - bs;
-        if (rem <= 0) break;
-        trsm_panel_kernel<<<(int)((rem + NB - 1) / NB), 64, 0, h->stream>>>(A, m, k0, bs, m);
-        GemmOp op{};
-        op.A = A + (k0 + bs) * m + k0; op.lda = m;      // L21 (rem x bs)
-        op.B = op.A; op.ldb = m;                        // L21 again, k-contiguous -> L21 L21^T
-        op.C = A + (k0 + bs) * m + (k0 + bs); op.ldc = m;
-        op.M = (int)rem; op.N = (int)rem; op.K = bs; op.lower_only = 1; op.alpha = -1.0; op.beta = 1.0;
-        set_op_kernel<<<1, 1, 0, h->stream>>>(h->chol_op + k, op);
-        ACC_TRY(launch_gemm_ops(h->chol_op + k, 1, (int)rem, (int)rem, false, h->stream));
+    for (int kprev = -1; kprev <= T - 2; ++kprev) {
+        const int kc = kprev + 1;
+        const int npanel = T - kc;
+        const int R = T - (kc + 1);
+        const int nupd = (kprev >= 0) ? R * (R + 1) / 2 : 0;
+        chol_step_kernel<<<npanel + nupd, NTHREADS, CHOL_LDS_BYTES, h->stream>>>(A, m, m, kprev, T, h->dscal,
+                                                                                 h->dflag);
     }
     prof_end(h, PROF_CHOL);
     ACC_HIP(hipGetLastError());

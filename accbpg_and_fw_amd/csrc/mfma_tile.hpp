@@ -224,6 +224,20 @@ struct Tile {
                     }
                 }
     }
+    // visit every accumulator element: f(row_in_tile, col_in_tile, value)
+    template <class F>
+    __device__ __forceinline__ void for_each(F&& f) {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+        const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    f(16 * (i * WAVES_M + wm) + lq + 4 * r, wn * WN + 16 * j + lr, (double)acc[i][j][r]);
+    }
     // raw accumulator slab (stream-K partials): [MI*NI*4][256] doubles, coalesced per register.
     __device__ __forceinline__ void store_slab(double* __restrict__ slab) const {
         const int tid = threadIdx.x;

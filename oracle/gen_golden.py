@@ -73,27 +73,34 @@ def percall(accbpg, tag, m, n, seed):
 
 
 def solver_traces(accbpg, tag, m, n, seed, iters):
+    """Whole-run traces.  The first five calls are the ones the reference's notebook makes on
+    this instance (ipynb/ex_Dopt_random.ipynb cells 1, 3, 5); the rest widen option coverage."""
     import numpy as np
     f, h, L, x0 = accbpg.D_opt_design(m, n, randseed=seed)
     out = {"m": m, "n": n, "seed": seed, "iters": iters}
     x, F, Ls, T = accbpg.BPG(f, h, L, x0, maxitrs=iters, linesearch=False, verbose=False)
     out.update(bpg_x=x, bpg_F=F, bpg_Ls=Ls)
-    x, F, Ls, T = accbpg.BPG(f, h, L, x0, maxitrs=iters, linesearch=True, ls_ratio=1.5, verbose=False)
+    x, F, Ls, T = accbpg.BPG(f, h, L, x0, maxitrs=iters, linesearch=True, verbose=False)
     out.update(bpgls_x=x, bpgls_F=F, bpgls_Ls=Ls)
-    x, F, G, T = accbpg.ABPG(f, h, L, x0, gamma=2, maxitrs=iters, theta_eq=False, verbose=False)
+    x, F, G, T = accbpg.ABPG(f, h, L, x0, gamma=2.0, maxitrs=iters, theta_eq=True, verbose=False)
     out.update(abpg_x=x, abpg_F=F, abpg_G=G)
-    x, F, G, T = accbpg.ABPG(f, h, L, x0, gamma=2, maxitrs=iters, theta_eq=True, restart=True,
-                             restart_rule='g', verbose=False)
+    x, F, G, T = accbpg.ABPG(f, h, L, x0, gamma=2.0, maxitrs=iters, theta_eq=True, restart=True, verbose=False)
     out.update(abpgrs_x=x, abpgrs_F=F, abpgrs_G=G)
-    x, F, Gain, Gdiv, Gavg, T = accbpg.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=iters, G0=0.1,
-                                                  ls_inc=1.5, ls_dec=1.5, restart=False, verbose=False)
+    x, F, Gain, Gdiv, Gavg, T = accbpg.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=iters, G0=0.1, theta_eq=True,
+                                                  verbose=False)
     out.update(gain_x=x, gain_F=F, gain_Gain=Gain, gain_Gdiv=Gdiv, gain_Gavg=Gavg)
+    x, F, Gain, Gdiv, Gavg, T = accbpg.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=iters, G0=0.1, theta_eq=True,
+                                                  restart=True, verbose=False)
+    out.update(gainrs_x=x, gainrs_F=F, gainrs_Gain=Gain, gainrs_Gdiv=Gdiv, gainrs_Gavg=Gavg)
+    # wider option coverage
+    x, F, G, T = accbpg.ABPG(f, h, L, x0, gamma=1.5, maxitrs=iters, theta_eq=False, verbose=False)
+    out.update(abpgk_x=x, abpgk_F=F, abpgk_G=G)
     x, F, Gain, Gdiv, Gavg, T = accbpg.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=iters, verbose=False)
     out.update(gaindef_x=x, gaindef_F=F, gaindef_Gain=Gain, gaindef_Gdiv=Gdiv, gaindef_Gavg=Gavg)
-    x, F, Gain, Gdiv, Gavg, T = accbpg.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=iters, G0=0.1,
-                                                  theta_eq=False, checkdiv=True, restart=True,
+    x, F, Gain, Gdiv, Gavg, T = accbpg.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=iters, G0=0.1, ls_inc=1.5,
+                                                  ls_dec=1.1, theta_eq=False, checkdiv=True, restart=True,
                                                   restart_rule='f', verbose=False)
-    out.update(gainrs_x=x, gainrs_F=F, gainrs_Gain=Gain, gainrs_Gdiv=Gdiv, gainrs_Gavg=Gavg)
+    out.update(gainopt_x=x, gainopt_F=F, gainopt_Gain=Gain, gainopt_Gdiv=Gdiv, gainopt_Gavg=Gavg)
     save("traces_" + tag, **out)
 
 
@@ -164,8 +171,19 @@ def main():
     ap.add_argument("--medium", action="store_true")
     ap.add_argument("--large", action="store_true")
     ap.add_argument("--only-large", action="store_true")
+    ap.add_argument("--only-traces", action="store_true")
+    ap.add_argument("--out", default=None, help="write into this directory instead of tests/golden")
     args = ap.parse_args()
     accbpg = load_reference()
+    if args.out:
+        global OUT
+        OUT = args.out
+    if args.only_traces:
+        solver_traces(accbpg, "80x200", 80, 200, 10, 1000)
+        solver_traces(accbpg, "80x120", 80, 120, 10, 300)
+        if args.medium:
+            solver_traces(accbpg, "256x4096", 256, 4096, 10, 1000)
+        return
     if not args.only_large:
         percall(accbpg, "80x200", 80, 200, 10)
         percall(accbpg, "128x1024", 128, 1024, 3)

@@ -178,22 +178,6 @@ def _close(a, b, tol):
     np.testing.assert_allclose(a, b, rtol=tol, atol=tol)
 
 
-def test_bpg_abpg_trajectories_80x200(acc):
-    """1000 iterations at the notebook instance D_opt_design(80,200,randseed=10): iterates within
-    the north-star tolerance l_inf < 1e-9, traces to 1e-9."""
-    gd = golden("traces_80x200")
-    f, h, L, x0 = acc.D_opt_design(80, 200, randseed=10)
-    x, F, Ls, T = acc.BPG(f, h, L, x0, maxitrs=1000, linesearch=False, verbose=False)
-    assert np.max(np.abs(x - gd["bpg_x"])) < 1e-9
-    _close(F, gd["bpg_F"], 1e-9)
-    assert "%.3e" % F[0] == "1.910e+01" and "%.3e" % F[900] == "1.759e+01"   # ipynb/ex_Dopt_random.ipynb:73,82
-    x, F, G, T = acc.ABPG(f, h, L, x0, gamma=2, maxitrs=1000, theta_eq=False, verbose=False)
-    assert np.max(np.abs(x - gd["abpg_x"])) < 1e-9
-    _close(F, gd["abpg_F"], 1e-9)
-    assert "%.3e" % G[100] == "5.529e-01"                                    # ipynb/ex_Dopt_random.ipynb:113
-    assert len(T) == len(F) and np.all(np.diff(T) >= 0)
-
-
 def _agree_prefix(a, b, tol):
     """length of the common prefix on which two traces agree to tol"""
     n = min(len(a), len(b))
@@ -201,47 +185,114 @@ def _agree_prefix(a, b, tol):
     return n if bad.size == 0 else int(bad[0])
 
 
-def test_linesearch_trajectories_80x200(acc):
-    """Line-search variants take discrete accept/reject decisions on quantities that sit at the
-    rounding floor once the run has converged (the reference itself moves by 4e-8 between 1 and 8
-    BLAS threads there), so: gains/L and F must agree exactly as long as they are decision-stable
-    (first 200 iterations), and the final objective must agree to 1e-10."""
+def test_bpg_abpg_trajectories_80x200(acc):
+    """1000 iterations at the notebook instance D_opt_design(80,200,randseed=10) with the notebook's
+    calls (ipynb/ex_Dopt_random.ipynb cells 1 and 3): iterates within the north-star tolerance
+    l_inf < 1e-9, traces to 1e-9, stored stdout rows reproduced."""
     gd = golden("traces_80x200")
     f, h, L, x0 = acc.D_opt_design(80, 200, randseed=10)
-    x, F, Ls, T = acc.BPG(f, h, L, x0, maxitrs=1000, linesearch=True, ls_ratio=1.5, verbose=False)
-    assert _agree_prefix(Ls, gd["bpgls_Ls"], 1e-12) >= 200
-    assert _agree_prefix(F, gd["bpgls_F"], 1e-10) >= 200
-    assert abs(F[-1] - gd["bpgls_F"][-1]) < 1e-10
-    x, F, Gain, Gdiv, Gavg, T = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=1000, G0=0.1, ls_inc=1.5,
-                                               ls_dec=1.5, verbose=False)
-    assert _agree_prefix(Gain, gd["gain_Gain"], 1e-12) >= 200
-    assert _agree_prefix(F, gd["gain_F"], 1e-10) >= 200
-    assert "%.3e" % Gain[0] == "2.488e-01" and "%.3e" % Gavg[0] == "4.988e-02"   # ex_Dopt_random.ipynb:282
-    assert abs(F[-1] - gd["gain_F"][-1]) < 1e-9
-    x, F, Gain, Gdiv, Gavg, T = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=1000, verbose=False)
-    assert _agree_prefix(Gain, gd["gaindef_Gain"], 1e-12) >= 200
-    assert abs(F[-1] - gd["gaindef_F"][-1]) < 1e-9
-    x, F, G, T = acc.ABPG(f, h, L, x0, gamma=2, maxitrs=1000, theta_eq=True, restart=True, restart_rule='g',
-                          verbose=False)
-    assert _agree_prefix(F, gd["abpgrs_F"], 1e-10) >= 100
-    x, F, Gain, Gdiv, Gavg, T = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=300, G0=0.1, theta_eq=False,
-                                               checkdiv=True, restart=True, restart_rule='f', verbose=False)
-    assert _agree_prefix(Gain, gd["gainrs_Gain"][:300], 1e-12) >= 100
+    x, F, Ls, T = acc.BPG(f, h, L, x0, maxitrs=1000, linesearch=False, verbose=False)
+    assert np.max(np.abs(x - gd["bpg_x"])) < 1e-9
+    _close(F, gd["bpg_F"], 1e-9)
+    assert "%.3e" % F[0] == "1.910e+01" and "%.3e" % F[900] == "1.759e+01"   # ex_Dopt_random.ipynb:73,82
+    x, F, Ls, T = acc.BPG(f, h, L, x0, maxitrs=1000, linesearch=True, verbose=False)
+    assert np.max(np.abs(x - gd["bpgls_x"])) < 1e-9
+    _close(F, gd["bpgls_F"], 1e-9); _close(Ls, gd["bpgls_Ls"], 1e-12)
+    assert "%.3e" % Ls[0] == "8.333e-01" and "%.3e" % Ls[100] == "1.938e-01"   # :243-244
+    x, F, G, T = acc.ABPG(f, h, L, x0, gamma=2.0, maxitrs=1000, theta_eq=True, verbose=False)
+    assert np.max(np.abs(x - gd["abpg_x"])) < 1e-9
+    _close(F, gd["abpg_F"], 1e-9); _close(G[:500], gd["abpg_G"][:500], 1e-6)
+    assert "%.3e" % G[100] == "5.529e-01"                                    # :113
+    assert len(T) == len(F) and np.all(np.diff(T) >= 0)
+    x, F, G, T = acc.ABPG(f, h, L, x0, gamma=2.0, maxitrs=1000, theta_eq=True, restart=True, verbose=False)
+    assert np.max(np.abs(x - gd["abpgrs_x"])) < 1e-9
+    x, F, G, T = acc.ABPG(f, h, L, x0, gamma=1.5, maxitrs=1000, theta_eq=False, verbose=False)
+    assert np.max(np.abs(x - gd["abpgk_x"])) < 1e-9
+    _close(F, gd["abpgk_F"], 1e-9)
+
+
+_GAIN_VARIANTS = [("gain", dict(G0=0.1, theta_eq=True)),
+                  ("gainrs", dict(G0=0.1, theta_eq=True, restart=True)),
+                  ("gaindef", dict()),
+                  ("gainopt", dict(G0=0.1, ls_inc=1.5, ls_dec=1.1, theta_eq=False, checkdiv=True,
+                                   restart=True, restart_rule='f'))]
+
+
+def _check_gain_runs(acc, tag, stable, tol_x):
+    """ABPG_gain takes discrete line-search decisions; once converged they sit at the rounding floor
+    and the reference itself is not reproducible across BLAS thread counts (first differs at k=756 on
+    (80,200), k=36..79 on (256,4096); tests/test_oracle.py).  So: identical gain sequence and F on the
+    decision-stable prefix (>= `stable` iterations), objective-level agreement at the end."""
+    gd = golden("traces_" + tag)
+    m, n, seed, iters = int(gd["m"]), int(gd["n"]), int(gd["seed"]), int(gd["iters"])
+    f, h, L, x0 = acc.D_opt_design(m, n, randseed=seed)
+    for key, kw in _GAIN_VARIANTS:
+        x, F, Gain, Gdiv, Gavg, T = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=iters, verbose=False, **kw)
+        ref_gain = gd[key + "_Gain"]
+        k = _agree_prefix(Gain, ref_gain, 1e-12)
+        assert k >= min(stable, len(ref_gain) - 5), (key, k)
+        ks = min(k, stable)
+        _close(F[:ks], gd[key + "_F"][:ks], 1e-9)           # decision-stable prefix: tight
+        _close(F[:k], gd[key + "_F"][:k], 1e-5)             # same decisions, rounding already amplified
+        _close(Gavg[:k], gd[key + "_Gavg"][:k], 1e-9)
+        assert len(F) == len(Gain) == len(Gdiv) == len(Gavg) == len(T)
+        nf = min(len(F), len(gd[key + "_F"]))
+        # after the decisions part ways only the objective level is comparable (the reference itself
+        # ends 1.5e-5 apart between 1 and 8 BLAS threads on (256,4096))
+        assert abs(F[nf - 1] - gd[key + "_F"][nf - 1]) < 1e-4
+        if k == len(ref_gain) == len(Gain):
+            assert np.max(np.abs(x - gd[key + "_x"])) < tol_x
+    return f, h, L, x0
+
+
+def test_abpg_gain_trajectories_80x200(acc):
+    f, h, L, x0 = _check_gain_runs(acc, "80x200", stable=400, tol_x=1e-9)
+    x, F, Gain, Gdiv, Gavg, T = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=200, G0=0.1, theta_eq=True,
+                                               verbose=False)
+    assert "%.3e" % Gain[0] == "2.488e-01" and "%.3e" % Gavg[0] == "4.988e-02"      # ex_Dopt_random.ipynb:282
+    assert "%.3e" % Gain[100] == "2.986e-01" and "%.3e" % Gdiv[100] == "7.091e-01"  # :283
 
 
 def test_early_stop_and_truncation_80x120(acc):
-    """Stopping rules and array truncation (algorithms.py:66-71,174-179,412-419)."""
+    """Stopping rules and array truncation (algorithms.py:66-71,174-179,412-419).  The stop tests
+    compare rounding-level quantities with 1e-14, so the stopping iteration may move by a few
+    iterations between summation orders; the traces must agree on the common prefix."""
     gd = golden("traces_80x120")
     f, h, L, x0 = acc.D_opt_design(80, 120, randseed=10)
     assert "%.3e" % f(x0) == "3.764e+01"                              # ex_Dopt_random.ipynb:398
     x, F, Ls, T = acc.BPG(f, h, L, x0, maxitrs=300, linesearch=False, verbose=False)
-    assert abs(len(F) - len(gd["bpg_F"])) <= 2 and len(F) == len(Ls) == len(T)
+    assert len(F) < 300 and len(F) == len(Ls) == len(T)
     n = min(len(F), len(gd["bpg_F"]))
+    assert n >= 40
     _close(F[:n], gd["bpg_F"][:n], 1e-10)
-    x, F, G, T = acc.ABPG(f, h, L, x0, gamma=2, maxitrs=300, verbose=False)
-    assert abs(len(F) - len(gd["abpg_F"])) <= 3
-    x, F, Gain, Gdiv, Gavg, T = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=300, verbose=False)
-    assert abs(len(F) - len(gd["gaindef_F"])) <= 5 and len(F) == len(Gain) == len(Gdiv) == len(Gavg)
+    x, F, G, T = acc.ABPG(f, h, L, x0, gamma=2.0, maxitrs=300, theta_eq=True, verbose=False)
+    n = min(len(F), len(gd["abpg_F"]))
+    assert len(F) < 300 and n >= 40
+    _close(F[:n], gd["abpg_F"][:n], 1e-10)
+    x, F, G, T = acc.ABPG(f, h, L, x0, gamma=2.0, maxitrs=300, theta_eq=True, restart=True, verbose=False)
+    n = min(len(F), len(gd["abpgrs_F"]))
+    assert n >= 20
+    _close(F[:n], gd["abpgrs_F"][:n], 1e-10)
+    _check_gain_runs(acc, "80x120", stable=15, tol_x=1e-8)
+    x, F, Gain, Gdiv, Gavg, T = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=50, G0=0.1, theta_eq=True,
+                                               verbose=False)
+    assert "%.3e" % Gain[0] == "5.160e-01" and "%.3e" % Gavg[0] == "7.183e-02"      # ex_Dopt_random.ipynb:398-418
+
+
+def test_trajectories_256x4096(acc):
+    """1000-iteration l_inf parity at a size where the CPU side is affordable."""
+    gd = golden("traces_256x4096")
+    f, h, L, x0 = acc.D_opt_design(256, 4096, randseed=10)
+    x, F, Ls, T = acc.BPG(f, h, L, x0, maxitrs=1000, linesearch=False, verbose=False)
+    assert np.max(np.abs(x - gd["bpg_x"])) < 1e-9
+    _close(F, gd["bpg_F"], 1e-9)
+    x, F, Ls, T = acc.BPG(f, h, L, x0, maxitrs=1000, linesearch=True, verbose=False)
+    assert np.max(np.abs(x - gd["bpgls_x"])) < 1e-9
+    _close(Ls, gd["bpgls_Ls"], 1e-12)
+    x, F, G, T = acc.ABPG(f, h, L, x0, gamma=2.0, maxitrs=1000, theta_eq=True, verbose=False)
+    assert np.max(np.abs(x - gd["abpg_x"])) < 1e-9
+    _close(F, gd["abpg_F"], 1e-9)
+    _check_gain_runs(acc, "256x4096", stable=30, tol_x=1e-9)
 
 
 def test_reference_loop_runs_on_device_objects(acc, O):
@@ -265,6 +316,7 @@ def test_housing_rng_free(acc):
     assert np.max(np.abs(x - gd["bpg_x"])) < 1e-9
     x, F, G, T = acc.ABPG(f, h, 1.0, x0, gamma=2, maxitrs=1001, verbose=False)
     _close(F, gd["abpg_F"], 1e-9)
+    assert np.max(np.abs(x - gd["abpg_x"])) < 1e-9
 
 
 # ------------------------------------------------------------------ Frank-Wolfe
