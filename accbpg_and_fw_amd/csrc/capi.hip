@@ -187,3 +187,8 @@ extern "C" int accbpg_test_gemm(const double* A_dev, int64_t lda, const double* 
     return launch_test_gemm(A_dev, lda, B_dev, ldb, C_dev, ldc, M, N, K, b_kmajor, alpha, beta, config,
                             (hipStream_t)stream);
 }
+
+extern "C" int accbpg_debug_gram_variant(accbpg_dopt* h, const double* x_dev, int variant, int iters, double* ms_host) {
+    if (!h || !x_dev || !ms_host || iters <= 0) return ACCBPG_ERR_ARG;
+    return debug_gram_variant(h, x_dev, variant, iters, ms_host);
+}

@@ -18,7 +18,9 @@ namespace accbpg {
 // a range that does not cover a whole tile leaves its raw accumulators in a slab, and the
 // fix-up kernel adds the slabs of a tile in workgroup order (deterministic, no atomics).
 // =========================================================================================
-template <class T>
+// VAR (timing ablations only, wrong results unless 0): 1 = no global loads in the steady state,
+// 2 = no scaling / LDS staging writes, 3 = neither and no barrier, 4 = additionally no fragment reads.
+template <class T, int VAR = 0>
 __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_kernel(
     const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n, const double* __restrict__ x,
     const TileRC* __restrict__ tiles, int ntiles, int64_t kiters, int64_t per, double* __restrict__ slabs,
@@ -37,26 +39,60 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_kernel(
         const int64_t row0 = (int64_t)tiles[tile].rb * T::BM;
         const int64_t col0 = (int64_t)tiles[tile].cb * T::BN;
         t.zero();
-        // prologue: stage k-step kb into buffer 0
+        // prologue: stage k-step kb into buffer 0, start the loads of k-step kb+1
         t.gload_A(V, ldv, row0, m, kb * BK, n, vec_ok);
         t.gload_B_kc(V, ldv, col0, m, kb * BK, n, vec_ok);
         t.scale_A(x, kb * BK, n);
         __syncthreads();              // previous segment's readers are done with the LDS buffers
         t.sstore(lds);
         __syncthreads();
+        // (the tail steps reload / restage the last tile redundantly: no branch in the steady state,
+        //  so the staging instructions can be scheduled between the MFMAs)
+        const int64_t klast = ke - 1;
+        {
+            const int64_t k1 = min(kb + 1, klast);
+            t.gload_A(V, ldv, row0, m, k1 * BK, n, vec_ok);
+            t.gload_B_kc(V, ldv, col0, m, k1 * BK, n, vec_ok);
+        }
+        t.template read_frag<0>(lds, 0);
         int cur = 0;
+        // Steady state of k-step ks (its tile is complete in buffer `cur`, the loads of tile ks+1 are
+        // in flight since the previous step, fragment group 0 is in register set 0):
+        //   groups 0..2 run with the next group's LDS reads in flight; tile ks+1 is scaled and
+        //   written to the other buffer in the shadow of group 2; ONE barrier; group 3 runs while
+        //   the loads of tile ks+2 are issued and group 0 of tile ks+1 is read.
+#pragma unroll 1
         for (int64_t ks = kb; ks < ke; ++ks) {
-            const bool more = ks + 1 < ke;
-            if (more) {
-                t.gload_A(V, ldv, row0, m, (ks + 1) * BK, n, vec_ok);
-                t.gload_B_kc(V, ldv, col0, m, (ks + 1) * BK, n, vec_ok);
+            const int64_t k1 = min(ks + 1, klast), k2 = min(ks + 2, klast);
+            const double* st = lds + cur * T::STAGE_ELEMS;
+            double* nx = lds + (cur ^ 1) * T::STAGE_ELEMS;
+            if constexpr (VAR < 4) t.template read_frag<1>(st, 1);
+            t.template mma_frag<0>();
+            if constexpr (VAR < 4) t.template read_frag<0>(st, 2);
+            t.template mma_frag<1>();
+            if constexpr (VAR < 4) t.template read_frag<1>(st, 3);
+            if constexpr (VAR == 0 || VAR == 1) {
+                t.scale_A(x, k1 * BK, n);
+                t.sstore(nx);
             }
-            t.compute(lds + cur * T::STAGE_ELEMS);
-            if (more) {
-                t.scale_A(x, (ks + 1) * BK, n);
-                t.sstore(lds + (cur ^ 1) * T::STAGE_ELEMS);
+            t.template mma_frag<0>();
+            if constexpr (T::MI * T::NI == 32 && !T::EDGE && VAR == 0)
+                sched_pre_barrier<32, T::MI + T::NI, 2 * T::A_PASS, T::A_PASS + T::B_PASS, 1>();
+            if constexpr (VAR < 3) __syncthreads();
+            if constexpr (VAR == 0 || VAR == 2) {
+                t.gload_A(V, ldv, row0, m, k2 * BK, n, vec_ok);
+                t.gload_B_kc(V, ldv, col0, m, k2 * BK, n, vec_ok);
             }
-            __syncthreads();
+            if constexpr (VAR == 2) {
+#pragma unroll
+                for (int p2 = 0; p2 < T::A_PASS; ++p2) asm volatile("" ::"v"(t.ra[p2]));
+#pragma unroll
+                for (int p2 = 0; p2 < T::B_PASS; ++p2) asm volatile("" ::"v"(t.rb[p2]));
+            }
+            if constexpr (VAR < 4) t.template read_frag<0>(nx, 0);
+            t.template mma_frag<1>();
+            if constexpr (T::MI * T::NI == 32 && !T::EDGE && VAR == 0)
+                sched_post_barrier<32, T::A_PASS + T::B_PASS, T::MI + T::NI>();
             cur ^= 1;
         }
         if (kb == 0 && ke == kiters) {
@@ -119,13 +155,19 @@ __global__ __launch_bounds__(NTHREADS, 1) void colnorm_kernel(
         __syncthreads();
         t.sstore(lds);
         __syncthreads();
+        const int64_t klast = ksteps - 1;
+        {
+            const int64_t k1 = min((int64_t)1, klast);
+            t.gload_A(W, ldw, row0, m, k1 * BK, Kend, vec_ok_w);
+            t.gload_B_km(V, ldv, col0, n, k1 * BK, Kend, vec_ok_v);
+        }
+        t.template read_frag<0>(lds, 0);
         int cur = 0;
+#pragma unroll 1
         for (int64_t ks = 0; ks < ksteps; ++ks) {
-            const bool more = ks + 1 < ksteps;
-            if (more) {
-                t.gload_A(W, ldw, row0, m, (ks + 1) * BK, Kend, vec_ok_w);
-                t.gload_B_km(V, ldv, col0, n, (ks + 1) * BK, Kend, vec_ok_v);
-            }
+            const int64_t k2 = min(ks + 2, klast);
+            const double* st = lds + cur * T::STAGE_ELEMS;
+            double* nx = lds + (cur ^ 1) * T::STAGE_ELEMS;
             // rows of this wave's fragment i are 16*(i*WAVES_M+wm)..+15; they are all zero in W
             // for this k-step when their last row is above the step's first column.
             const int64_t kd = ks * BK - row0;
@@ -134,9 +176,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void colnorm_kernel(
                 const int64_t num = kd - 15 - 16 * wm;
                 mi_lo = num > 0 ? (int)((num + 16 * T::WAVES_M - 1) / (16 * T::WAVES_M)) : 0;
             }
-            t.compute(lds + cur * T::STAGE_ELEMS, mi_lo);
-            if (more) t.sstore(lds + (cur ^ 1) * T::STAGE_ELEMS);
+            t.template read_frag<1>(st, 1);
+            t.template mma_frag<0>(mi_lo);
+            t.template read_frag<0>(st, 2);
+            t.template mma_frag<1>(mi_lo);
+            t.template read_frag<1>(st, 3);
+            t.sstore(nx);
+            t.template mma_frag<0>(mi_lo);
             __syncthreads();
+            t.gload_A(W, ldw, row0, m, k2 * BK, Kend, vec_ok_w);
+            t.gload_B_km(V, ldv, col0, n, k2 * BK, Kend, vec_ok_v);
+            t.template read_frag<0>(nx, 0);
+            t.template mma_frag<1>(mi_lo);
             cur ^= 1;
         }
         // square and add this row block's Y into the per-column sums (rows beyond m are zero)
@@ -788,6 +839,44 @@ static void gram_launch_t(accbpg_dopt* h, const double* x, double* gram) {
     gram_fixup_kernel<T><<<h->ntiles, NTHREADS, 0, h->stream>>>(h->tiles, h->ntiles, h->kiters, h->gram_per,
                                                                 h->slabs, gram, h->m, h->m);
     prof_end(h, PROF_GRAMFIX);
+}
+
+// timing ablations of the Gram kernel (big interior tile only); returns average ms over `iters`
+int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, double* ms_out) {
+    using T = TileBig<false, false>;
+    if (!h->big) return ACCBPG_ERR_ARG;
+    hipEvent_t a, b;
+    ACC_HIP(hipEventCreate(&a));
+    ACC_HIP(hipEventCreate(&b));
+    auto launch = [&]() {
+#define ACC_LAUNCH_VAR(VV)                                                                                       \
+    gram_streamk_kernel<T, VV><<<h->gram_grid, NTHREADS, T::LDS_BYTES, h->stream>>>(                             \
+        h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->slabs, h->Tbuf, h->m, h->vec_ok)
+        switch (var) {
+            case 0: ACC_LAUNCH_VAR(0); break;
+            case 1: ACC_LAUNCH_VAR(1); break;
+            case 2: ACC_LAUNCH_VAR(2); break;
+            case 3: ACC_LAUNCH_VAR(3); break;
+            default: ACC_LAUNCH_VAR(4); break;
+        }
+#undef ACC_LAUNCH_VAR
+    };
+    ACC_TRY(set_lds(gram_streamk_kernel<T, 1>, T::LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_kernel<T, 2>, T::LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_kernel<T, 3>, T::LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_kernel<T, 4>, T::LDS_BYTES));
+    launch();
+    ACC_HIP(hipEventRecord(a, h->stream));
+    for (int i = 0; i < iters; ++i) launch();
+    ACC_HIP(hipEventRecord(b, h->stream));
+    ACC_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    ACC_HIP(hipEventElapsedTime(&ms, a, b));
+    *ms_out = ms / iters;
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    ACC_HIP(hipGetLastError());
+    return ACCBPG_OK;
 }
 
 int launch_gram(accbpg_dopt* h, const double* x, double* gram) {

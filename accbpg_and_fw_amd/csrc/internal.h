@@ -105,6 +105,7 @@ int launch_test_gemm(const double* A, int64_t lda, const double* B, int64_t ldb,
                      int64_t M, int64_t N, int64_t K, int b_kmajor, double alpha, double beta, int config,
                      hipStream_t s);
 int build_plans(accbpg_dopt* h);
+int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, double* ms_out);
 int mfma_peak(int iters, double* tflops, hipStream_t s);
 
 // vec_kernels.hip

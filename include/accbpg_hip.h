@@ -160,6 +160,11 @@ int accbpg_test_gemm(const double* A_dev, int64_t lda, const double* B_dev, int6
                      double* C_dev, int64_t ldc, int64_t M, int64_t N, int64_t K,
                      int b_kmajor, double alpha, double beta, int config, void* stream);
 
+/* Timing ablations of the Gram kernel (development aid; variant 0 is the product kernel, the
+ * others drop global loads / LDS staging / the barrier / fragment reads and produce wrong data
+ * into scratch).  Average milliseconds per launch over `iters` launches. */
+int accbpg_debug_gram_variant(accbpg_dopt* h, const double* x_dev, int variant, int iters, double* ms_host);
+
 #ifdef __cplusplus
 }
 #endif
