@@ -27,7 +27,7 @@ _P = C.c_void_p
 _SIGS = {
     "accbpg_abi_version": (C.c_int, []),
     "accbpg_last_error": (C.c_char_p, []),
-    "accbpg_dopt_create": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _P, C.POINTER(_P)]),
+    "accbpg_dopt_create": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _P, C.POINTER(_P), C.c_int]),
     "accbpg_dopt_destroy": (C.c_int, [_P]),
     "accbpg_dopt_set_stream": (C.c_int, [_P, _P]),
     "accbpg_dopt_func_grad": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_double), _P]),

@@ -38,13 +38,13 @@ extern "C" int accbpg_abi_version(void) { return 1; }
 extern "C" const char* accbpg_last_error(void) { return g_err; }
 
 extern "C" int accbpg_dopt_create(const double* V_dev, int64_t m, int64_t n, int64_t ldv, void* stream,
-                                  accbpg_dopt** out) {
+                                  accbpg_dopt** out, int is_shard) {
     if (!V_dev || !out || m <= 0 || n <= 0 || ldv < n) {
         set_last_error("accbpg_dopt_create: bad arguments (m=%lld n=%lld ldv=%lld)", (long long)m, (long long)n,
                        (long long)ldv);
         return ACCBPG_ERR_ARG;
     }
-    if (!(m < n)) {                         // DOptimalObj: need m < n   (functions.py:35)
+    if (!is_shard && !(m < n)) {            // DOptimalObj: need m < n   (functions.py:35)
         set_last_error("DOptimalObj: need m < n");
         return ACCBPG_ERR_ASSERT;
     }

@@ -86,16 +86,18 @@ class DOptimalObj(RSmoothFunction):
     (borrowed).  ``self.H``, ``self.m``, ``self.n`` stay readable as in the
     reference (callers use ``f.H``)."""
 
-    def __init__(self, H):
+    def __init__(self, H, _shard=False):
         self.H = H
         self.m = H.shape[0]
         self.n = H.shape[1]
-        assert self.m < self.n, "DOptimalObj: need m < n"
+        # a column shard of a larger instance may have fewer columns than rows
+        assert _shard or self.m < self.n, "DOptimalObj: need m < n"
         self._V, _ = to_dev(H)
         lib = _lib.load()
         h = C.c_void_p()
         with torch.cuda.device(self._V.device):
-            rc = lib.accbpg_dopt_create(_ptr(self._V), self.m, self.n, self._V.stride(0), _stream(), C.byref(h))
+            rc = lib.accbpg_dopt_create(_ptr(self._V), self.m, self.n, self._V.stride(0), _stream(), C.byref(h),
+                                        1 if _shard else 0)
         _lib.check(rc, "accbpg_dopt_create")
         self._h = h
         self._lib = lib

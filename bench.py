@@ -37,6 +37,10 @@ def parse():
     ap.add_argument("--workload", default="abpg_gain", choices=["abpg_gain", "abpg", "bpg", "fw", "fw_away"])
     ap.add_argument("--m", type=int, default=2048)
     ap.add_argument("--n", type=int, default=32768)
+    ap.add_argument("--mode", default="instances", choices=["instances", "shard"],
+                    help="N>1: 'instances' = one independent instance per GPU (weak scaling, default); "
+                         "'shard' = ONE instance, design points partitioned over the GPUs with one RCCL "
+                         "all-reduce of the Gram matrix per evaluation (strong scaling, BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=1)
     return ap.parse_args()
@@ -91,8 +95,21 @@ def main():
     from accbpg_and_fw_amd import algorithms as alg
 
     m, n = args.m, args.n
-    V = make_instance(m, n, 1 + rank, device)
-    f = acc.DOptimalObj(V)
+    shard = (args.mode == "shard" and world > 1)
+    if shard:
+        # synthetic standard-normal design points generated on the device, per shard (the whole
+        # matrix of config 5 is 16 GiB and never exists on one host)
+        from accbpg_and_fw_amd.sharded import make_sharded, shard_bounds
+        lo, hi = shard_bounds(n, world, rank)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(1000 + rank)
+        V = torch.randn(m, hi - lo, dtype=torch.float64, device=device, generator=gen)
+        f = make_sharded(V, m, n, rank, world)
+        prof_obj = f.local
+    else:
+        V = make_instance(m, n, 1 + rank, device)
+        f = acc.DOptimalObj(V)
+        prof_obj = f
     h = acc.BurgEntropySimplex()
     x0 = torch.full((n,), 1.0 / n, dtype=torch.float64, device=device)
     total = args.warmup + args.steps
@@ -116,9 +133,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if shard and args.workload.startswith("fw"):
+        raise SystemExit("shard mode covers the BPG family (the FW solvers are not a multi-GPU config)")
     for _ in range(args.warmup):
         step()
-    f.profile(True)
+    prof_obj.profile(True)
     calls0 = dict(f.calls)
     barrier()
     t0 = time.perf_counter()
@@ -126,8 +145,8 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = f.profile_read()
-    f.profile(False)
+    prof = prof_obj.profile_read()
+    prof_obj.profile(False)
     calls = {k: f.calls[k] - calls0[k] for k in calls0}
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -136,15 +155,17 @@ def main():
     tmax = float(tmax.item())
 
     if rank == 0:
-        value = world * args.steps / tmax
+        value = (1 if shard else world) * args.steps / tmax
         out = {
             "metric": "D-opt iters/sec (m=%d,n=%d)" % (m, n),
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * tmax / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "D_opt_design(%d,%d) %s%s fp64, one independent instance per GPU"
-                                   % (m, n, args.workload, " gamma=2" if "bpg" in args.workload and args.workload != "bpg" else ""),
-                       "instances": world, "seeds": "1..%d" % world,
+            "scaling": "strong" if shard else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "D_opt_design(%d,%d) %s%s fp64, %s"
+                                   % (m, n, args.workload, " gamma=2" if "bpg" in args.workload and args.workload != "bpg" else "",
+                                      "ONE instance, design points sharded over the GPUs, one RCCL all-reduce of the Gram matrix per evaluation"
+                                      if shard else "one independent instance per GPU"),
+                       "instances": 1 if shard else world, "seeds": "1..%d" % world,
                        "oracle_calls_per_step": {k: v / args.steps for k, v in calls.items()}},
         }
         gram_ms, gram_cnt = prof["gram"]

@@ -43,9 +43,11 @@ const char* accbpg_last_error(void);
 
 /* Borrow V (m x n, row-major, leading dimension ldv >= n; the reference's `self.H`,
  * functions.py:32).  V must outlive the handle.  The handle owns all workspace
- * (Gram matrix, Cholesky factor, inverse factor, stream-K slabs, pinned scalars). */
+ * (Gram matrix, Cholesky factor, inverse factor, stream-K slabs, pinned scalars).
+ * is_shard != 0: V is a column block of a larger instance (design-point sharding), so the
+ * reference's m < n precondition (functions.py:35) applies to the whole instance, not to it. */
 int accbpg_dopt_create(const double* V_dev, int64_t m, int64_t n, int64_t ldv,
-                       void* stream, accbpg_dopt** out);
+                       void* stream, accbpg_dopt** out, int is_shard);
 int accbpg_dopt_destroy(accbpg_dopt* h);
 int accbpg_dopt_set_stream(accbpg_dopt* h, void* stream);
 

@@ -412,3 +412,29 @@ def test_large_fw_2048x32768(large, acc):
     x, F, SP, SN, T = acc.D_opt_FW_away(f, x0, 1e-8, 40, verbose=False)
     assert np.max(np.abs(x - gd["away_x"])) < 1e-9
     _close(F, gd["away_F"], 1e-8); _close(SP, gd["away_SP"], 1e-9)
+
+
+# ------------------------------------------------------------------ sharding (one device, logical shards)
+@pytest.mark.parametrize("shape,parts", [((96, 1000), 3), ((1024, 4096), 8), ((300, 1111), 4)])
+def test_logical_shards_match_single_device(acc, shape, parts):
+    """Design-point sharding with the all-reduce replaced by an in-process sum:
+    same f and g as the unsharded objective, and a solver runs on it unchanged."""
+    from accbpg_and_fw_amd.sharded import LogicalShards
+    m, n = shape
+    V = gaussian_design(m, n, 11)
+    rng = np.random.RandomState(3)
+    x = rng.rand(n) + 0.01
+    x /= x.sum()
+    f = acc.DOptimalObj(V)
+    fs = LogicalShards(V, parts)
+    f1, g1 = f.func_grad(x, 2)
+    f2, g2 = fs.func_grad(x, 2)
+    assert abs(f1 - f2) < 1e-11 * max(1.0, abs(f1))
+    np.testing.assert_allclose(g2, g1, rtol=1e-11)
+    assert fs(x) == f2
+    h = acc.BurgEntropySimplex()
+    x0 = np.ones(n) / n
+    xa, Fa, Ga, Ta = acc.ABPG(f, h, 1.0, x0, gamma=2, maxitrs=15, verbose=False)
+    xb, Fb, Gb, Tb = acc.ABPG(fs, h, 1.0, x0, gamma=2, maxitrs=15, verbose=False)
+    assert np.max(np.abs(xa - xb)) < 1e-12
+    np.testing.assert_allclose(Fb, Fa, rtol=1e-12, atol=1e-12)
