@@ -105,11 +105,13 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_kernel(
     }
 }
 
+// grid = ntiles * T::MI: workgroup (tile, part) sums fragment row `part` of the tile's slabs, so
+// the reduction reads the slabs with MI times the workgroups (HBM-bound pass, not 72 CUs' worth)
 template <class T>
-__global__ __launch_bounds__(NTHREADS, 1) void gram_fixup_kernel(
+__global__ __launch_bounds__(NTHREADS, 2) void gram_fixup_kernel(
     const TileRC* __restrict__ tiles, int ntiles, int64_t kiters, int64_t per, const double* __restrict__ slabs,
     double* __restrict__ G, int64_t ldg, int64_t m) {
-    const int tile = blockIdx.x;
+    const int tile = blockIdx.x / T::MI, part = blockIdx.x % T::MI;
     const int64_t first_it = (int64_t)tile * kiters, last_it = first_it + kiters - 1;
     const int64_t w0 = first_it / per, w1 = last_it / per;
     // both ends of the tile inside one workgroup's range: that workgroup ran it as one whole
@@ -120,9 +122,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_fixup_kernel(
     for (int64_t w = w0; w <= w1; ++w) {
         const int64_t wfirst_tile = (w * per) / kiters;
         const int slot = (wfirst_tile == tile) ? 0 : 1;
-        t.add_slab(slabs + (w * 2 + slot) * T::SLAB_DOUBLES);
+        t.add_slab_part(slabs + (w * 2 + slot) * T::SLAB_DOUBLES, part);
     }
-    t.store_C(G, ldg, (int64_t)tiles[tile].rb * T::BM, (int64_t)tiles[tile].cb * T::BN, m, m, 1.0, 0.0, true);
+    t.store_C_part(G, ldg, (int64_t)tiles[tile].rb * T::BM, (int64_t)tiles[tile].cb * T::BN, m, m, true, part);
 }
 
 // =========================================================================================
@@ -836,7 +838,7 @@ static void gram_launch_t(accbpg_dopt* h, const double* x, double* gram) {
         h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->slabs, gram, h->m, h->vec_ok);
     prof_end(h, PROF_GRAM);
     prof_begin(h, PROF_GRAMFIX);
-    gram_fixup_kernel<T><<<h->ntiles, NTHREADS, 0, h->stream>>>(h->tiles, h->ntiles, h->kiters, h->gram_per,
+    gram_fixup_kernel<T><<<h->ntiles * T::MI, NTHREADS, 0, h->stream>>>(h->tiles, h->ntiles, h->kiters, h->gram_per,
                                                                 h->slabs, gram, h->m, h->m);
     prof_end(h, PROF_GRAMFIX);
 }

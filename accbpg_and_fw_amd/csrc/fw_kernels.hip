@@ -8,7 +8,6 @@
 namespace accbpg {
 
 constexpr int FB = 256;
-constexpr int PROBE_T = 1024;
 constexpr int VG_COLS = 2 * FB;      // columns of V per workgroup in the V^T Hv pass
 constexpr int VG_MAXSPLIT = 64;
 
@@ -31,8 +30,8 @@ __device__ __forceinline__ ValIdx shfl_down_vi(ValIdx a, int off) {
     return r;
 }
 
-template <bool IS_MAX>
-__device__ __forceinline__ ValIdx block_reduce_vi(ValIdx a, ValIdx* sh) {
+template <bool IS_MAX, int NT>
+__device__ __forceinline__ ValIdx block_reduce_vi_n(ValIdx a, ValIdx* sh) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         ValIdx o = shfl_down_vi(a, off);
@@ -43,41 +42,61 @@ __device__ __forceinline__ ValIdx block_reduce_vi(ValIdx a, ValIdx* sh) {
     if (lane == 0) sh[w] = a;
     __syncthreads();
     ValIdx r = sh[0];
-    for (int i = 1; i < PROBE_T / 64; ++i) r = IS_MAX ? better_max(r, sh[i]) : better_min(r, sh[i]);
+    for (int i = 1; i < NT / 64; ++i) r = IS_MAX ? better_max(r, sh[i]) : better_min(r, sh[i]);
     return r;
 }
 
-// One workgroup scans w and x: i = argmax w; then the away index.
-//   away == 0: min of w over {x > 0}                               (D_opt_alg.py:60-61)
-//   away == 1: j = argmin (w - w_i) * [x > 1e-8], first index      (D_opt_alg.py:146-147)
-// out: {i, j} as doubles would lose range, so indices go to iout[0..1]; dout = {w_i, w_j, x_j}.
-__global__ __launch_bounds__(PROBE_T) void fw_probe_kernel(const double* __restrict__ w,
-                                                          const double* __restrict__ x, int64_t n, int away,
-                                                          double* __restrict__ dout, int64_t* __restrict__ iout) {
-    __shared__ ValIdx sh[PROBE_T / 64];
+// Probe, stage 1 (one pass over w and x, many workgroups): per-block first-index argmax of w and
+// first-index argmin of w over the support mask (away: x > 1e-8, D_opt_alg.py:147; FW: x > 0, :60).
+//
+// Why one pass is enough for the away index j = argmin((w - w_i) * [x > 1e-8]) (:146-147): with
+// w_i the maximum, every masked entry is <= 0 and every unmasked entry is (-)0.  If some masked
+// w_k < w_i the minimum is the masked entry with the smallest w (first index on ties -- equal w give
+// equal differences); otherwise all entries are zero and NumPy's argmin returns index 0.
+__global__ __launch_bounds__(FB) void fw_probe_partial_kernel(const double* __restrict__ w,
+                                                             const double* __restrict__ x, int64_t n, int away,
+                                                             ValIdx* __restrict__ part) {
+    __shared__ ValIdx sh[FB / 64];
     const double inf = __builtin_inf();
-    ValIdx best{-inf, INT64_MAX};
-    for (int64_t k = threadIdx.x; k < n; k += PROBE_T) best = better_max(best, ValIdx{w[k], k});
-    const ValIdx mx = block_reduce_vi<true>(best, sh);
-    ValIdx lo{inf, INT64_MAX};
-    if (away) {
-        for (int64_t k = threadIdx.x; k < n; k += PROBE_T) {
-            const double ww = w[k] - mx.v;                     // ww = w - w[i]
-            const double mask = (x[k] > 1.0e-8) ? 1.0 : 0.0;
-            lo = better_min(lo, ValIdx{ww * mask, k});         // -0.0 == 0.0 ties resolve by index
-        }
-    } else {
-        for (int64_t k = threadIdx.x; k < n; k += PROBE_T)
-            if (x[k] > 0.0) lo = better_min(lo, ValIdx{w[k], k});
+    const double thr = away ? 1.0e-8 : 0.0;
+    ValIdx best{-inf, INT64_MAX}, lo{inf, INT64_MAX};
+    const int64_t stride = (int64_t)gridDim.x * FB;
+    for (int64_t k = (int64_t)blockIdx.x * FB + threadIdx.x; k < n; k += stride) {
+        const double wk = w[k];
+        best = better_max(best, ValIdx{wk, k});
+        if (x[k] > thr) lo = better_min(lo, ValIdx{wk, k});
     }
-    const ValIdx mn = block_reduce_vi<false>(lo, sh);
+    const ValIdx mx = block_reduce_vi_n<true, FB>(best, sh);
+    const ValIdx mn = block_reduce_vi_n<false, FB>(lo, sh);
     if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = mx;
+        part[2 * blockIdx.x + 1] = mn;
+    }
+}
+
+// stage 2: combine the partials (block order), resolve the all-zero case, fetch w_j and x_j
+__global__ __launch_bounds__(FB) void fw_probe_final_kernel(const ValIdx* __restrict__ part, int nblk,
+                                                           const double* __restrict__ w,
+                                                           const double* __restrict__ x, int64_t n, int away,
+                                                           double* __restrict__ dout, int64_t* __restrict__ iout) {
+    __shared__ ValIdx sh[FB / 64];
+    const double inf = __builtin_inf();
+    ValIdx best{-inf, INT64_MAX}, lo{inf, INT64_MAX};
+    for (int b = threadIdx.x; b < nblk; b += FB) {
+        best = better_max(best, part[2 * b]);
+        lo = better_min(lo, part[2 * b + 1]);
+    }
+    const ValIdx mx = block_reduce_vi_n<true, FB>(best, sh);
+    const ValIdx mn = block_reduce_vi_n<false, FB>(lo, sh);
+    if (threadIdx.x == 0) {
+        int64_t j = mn.i;
+        if (away && !(mn.v < mx.v)) j = 0;                 // every shifted, masked entry is zero
         iout[0] = mx.i;
-        iout[1] = mn.i;
+        iout[1] = j;
         dout[0] = mx.v;
-        const bool ok = mn.i >= 0 && mn.i < n;
-        dout[1] = ok ? w[mn.i] : inf;
-        dout[2] = ok ? x[mn.i] : 0.0;
+        const bool ok = j >= 0 && j < n;
+        dout[1] = ok ? w[j] : inf;
+        dout[2] = ok ? x[j] : 0.0;
     }
 }
 
@@ -200,7 +219,7 @@ static int fw_alloc(accbpg_dopt* h) {
     ACC_HIP(hipMalloc(&h->fw_x, sizeof(double) * h->n));
     ACC_HIP(hipMalloc(&h->fw_w, sizeof(double) * h->n));
     ACC_HIP(hipMalloc(&h->fw_H, sizeof(double) * h->m * h->m));
-    ACC_HIP(hipMalloc(&h->fw_hv, sizeof(double) * 2 * h->m));
+    ACC_HIP(hipMalloc(&h->fw_hv, sizeof(double) * (2 * h->m + 2 * 1024 + 16)));   // Hv, vp, probe partials
     return ACCBPG_OK;
 }
 
@@ -262,7 +281,12 @@ extern "C" int accbpg_fw_probe_step(accbpg_dopt* h, int away, int refresh_logdet
         if (fl[FLAG_NOT_PD]) logdet = __builtin_nan("");
     }
     int64_t* iout = reinterpret_cast<int64_t*>(h->dscal + 8);
-    fw_probe_kernel<<<1, PROBE_T, 0, h->stream>>>(h->fw_w, h->fw_x, h->n, away, h->dscal + 4, iout);
+    int nblk = (int)((h->n + (int64_t)FB * 8 - 1) / ((int64_t)FB * 8));
+    if (nblk < 1) nblk = 1;
+    if (nblk > 512) nblk = 512;
+    ValIdx* part = reinterpret_cast<ValIdx*>(h->fw_hv + 2 * h->m);      // 2*512 records behind Hv / vp
+    fw_probe_partial_kernel<<<nblk, FB, 0, h->stream>>>(h->fw_w, h->fw_x, h->n, away, part);
+    fw_probe_final_kernel<<<1, FB, 0, h->stream>>>(part, nblk, h->fw_w, h->fw_x, h->n, away, h->dscal + 4, iout);
     ACC_HIP(hipGetLastError());
     ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * 12, hipMemcpyDeviceToHost, h->stream));
     ACC_HIP(hipStreamSynchronize(h->stream));

@@ -273,6 +273,36 @@ struct Tile {
                 for (int r = 0; r < 4; ++r) acc[i][j][r] += slab[((i * NI + j) * 4 + r) * NTHREADS + tid];
     }
     static constexpr int SLAB_DOUBLES = MI * NI * 4 * NTHREADS;   // == BM*BN
+    // fix-up on a quarter-tile: only fragment row `part` (of MI) is summed and stored
+    __device__ __forceinline__ void add_slab_part(const double* __restrict__ slab, int part) {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+            if (i == part) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += slab[((i * NI + j) * 4 + r) * NTHREADS + tid];
+            }
+    }
+    __device__ __forceinline__ void store_C_part(double* __restrict__ C, int64_t ldc, int64_t row0, int64_t col0,
+                                                 int64_t M, int64_t N, bool lower_only, int part) const {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+        const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+            if (i == part) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t row = row0 + 16 * (i * WAVES_M + wm) + lq + 4 * r;
+                        const int64_t col = col0 + wn * WN + 16 * j + lr;
+                        if (row < M && col < N && !(lower_only && col > row)) C[row * ldc + col] = acc[i][j][r];
+                    }
+            }
+    }
 };
 
 // Scheduling pipelines (LLVM sched_group_barrier) for the software-pipelined main loops of the big

@@ -251,10 +251,11 @@ __global__ __launch_bounds__(RB) void axpby_kernel(double a, const double* __res
 }
 
 // -----------------------------------------------------------------------------------------
-static double* g_pin = nullptr;       // pinned host scratch (16 doubles)
-static int* g_flags = nullptr;        // device flags for the handle-free entry points
-static int* g_info = nullptr;         // device {bisection, newton}
-static double* g_out = nullptr;       // device result scalars
+// per host thread (instances of a batch are driven from separate threads on separate streams)
+static thread_local double* g_pin = nullptr;       // pinned host scratch (32 doubles)
+static thread_local int* g_flags = nullptr;        // device flags for the handle-free entry points
+static thread_local int* g_info = nullptr;         // device {bisection, newton}
+static thread_local double* g_out = nullptr;       // device result scalars
 
 static int ensure_scratch() {
     if (g_pin) return ACCBPG_OK;

@@ -11,6 +11,7 @@ libaccbpg_hip.so; torch only owns memory and streams.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -51,12 +52,12 @@ def _ptr(t):
 
 
 class _Workspace:
-    """Scratch for the length-n kernels, one per (device, n)."""
+    """Scratch for the length-n kernels, one per (host thread, device, n)."""
     _cache = {}
 
     @classmethod
     def get(cls, n, device):
-        key = (device.index, int(n))
+        key = (threading.get_ident(), device.index, int(n))
         ws = cls._cache.get(key)
         if ws is None:
             size = _lib.load().accbpg_vec_workspace_doubles(int(n))

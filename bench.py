@@ -41,8 +41,11 @@ def parse():
                     help="N>1: 'instances' = one independent instance per GPU (weak scaling, default); "
                          "'shard' = ONE instance, design points partitioned over the GPUs with one RCCL "
                          "all-reduce of the Gram matrix per evaluation (strong scaling, BASELINE config 5)")
+    ap.add_argument("--instances-per-gpu", type=int, default=1,
+                    help="independent instances per GPU driven concurrently from host threads on separate "
+                         "streams (BASELINE config 4: 64 x D_opt_design(512,8192) over 8 GPUs = 8 per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=1)
+    ap.add_argument("--cpu-iters", type=int, default=3)
     return ap.parse_args()
 
 
@@ -114,7 +117,22 @@ def main():
     x0 = torch.full((n,), 1.0 / n, dtype=torch.float64, device=device)
     total = args.warmup + args.steps
 
-    if args.workload == "abpg_gain":
+    ipg = max(1, args.instances_per_gpu)
+    batch = None
+    if ipg > 1:
+        if shard or args.workload.startswith("fw"):
+            raise SystemExit("--instances-per-gpu applies to the BPG family in instances mode")
+        from accbpg_and_fw_amd.batched import BatchStepper
+        objs = [f] + [acc.DOptimalObj(make_instance(m, n, 1 + rank + 1000 * j, device)) for j in range(1, ipg)]
+        steps_fn = {"abpg_gain": lambda ff: alg.ABPG_gain_steps(ff, acc.BurgEntropySimplex(), 1.0, x0.clone(), 2,
+                                                                total + 1, verbose=False),
+                    "abpg": lambda ff: alg.ABPG_steps(ff, acc.BurgEntropySimplex(), 1.0, x0.clone(), 2, total + 1,
+                                                      verbose=False),
+                    "bpg": lambda ff: alg.BPG_steps(ff, acc.BurgEntropySimplex(), 1.0, x0.clone(), total + 1,
+                                                    verbose=False)}[args.workload]
+        batch = BatchStepper([(lambda ff=ff: steps_fn(ff)) for ff in objs], device, threads=ipg)
+        step = batch.step
+    elif args.workload == "abpg_gain":
         gen = alg.ABPG_gain_steps(f, h, 1.0, x0, 2, total + 1, verbose=False)
         step = lambda: next(gen)
     elif args.workload == "abpg":
@@ -135,14 +153,20 @@ def main():
 
     if shard and args.workload.startswith("fw"):
         raise SystemExit("shard mode covers the BPG family (the FW solvers are not a multi-GPU config)")
-    for _ in range(args.warmup):
-        step()
-    prof_obj.profile(True)
+    if batch is not None:
+        batch.step(args.warmup)
+    else:
+        for _ in range(args.warmup):
+            step()
+    prof_obj.profile(ipg == 1)
     calls0 = dict(f.calls)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    if batch is not None:
+        batch.step(args.steps)          # every instance advances args.steps outer iterations
+    else:
+        for _ in range(args.steps):
+            step()
     barrier()
     elapsed = time.perf_counter() - t0
     prof = prof_obj.profile_read()
@@ -155,7 +179,7 @@ def main():
     tmax = float(tmax.item())
 
     if rank == 0:
-        value = (1 if shard else world) * args.steps / tmax
+        value = (1 if shard else world * ipg) * args.steps / tmax
         out = {
             "metric": "D-opt iters/sec (m=%d,n=%d)" % (m, n),
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
@@ -165,7 +189,8 @@ def main():
                                    % (m, n, args.workload, " gamma=2" if "bpg" in args.workload and args.workload != "bpg" else "",
                                       "ONE instance, design points sharded over the GPUs, one RCCL all-reduce of the Gram matrix per evaluation"
                                       if shard else "one independent instance per GPU"),
-                       "instances": 1 if shard else world, "seeds": "1..%d" % world,
+                       "instances": 1 if shard else world * ipg, "instances_per_gpu": ipg,
+                       "seeds": "1..%d" % world,
                        "oracle_calls_per_step": {k: v / args.steps for k, v in calls.items()}},
         }
         gram_ms, gram_cnt = prof["gram"]
