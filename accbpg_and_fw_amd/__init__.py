@@ -11,10 +11,14 @@ ctypes C-ABI (include/accbpg_hip.h); there is no CPU fallback.
 """
 from .functions import (RSmoothFunction, DOptimalObj, LegendreFunction, BurgEntropy,
                         BurgEntropySimplex)
-from .algorithms import BPG, ABPG, ABPG_gain, solve_theta
+from .algorithms import BPG, ABPG, ABPG_gain, ABPG_expo, ABDA, solve_theta
+from .algorithms_fw import FW_alg_div_step
+from .functions_lmo import lmo_simplex
 from .D_opt_alg import D_opt_FW, D_opt_FW_away
-from .applications import D_opt_design
+from .applications import D_opt_design, D_opt_libsvm, D_opt_KYinit
+from .utils import load_libsvm_file
 
 __all__ = ["RSmoothFunction", "DOptimalObj", "LegendreFunction", "BurgEntropy", "BurgEntropySimplex",
-           "BPG", "ABPG", "ABPG_gain", "solve_theta", "D_opt_FW", "D_opt_FW_away", "D_opt_design"]
+           "BPG", "ABPG", "ABPG_gain", "ABPG_expo", "ABDA", "solve_theta", "FW_alg_div_step", "lmo_simplex",
+           "D_opt_FW", "D_opt_FW_away", "D_opt_design", "D_opt_libsvm", "D_opt_KYinit", "load_libsvm_file"]
 __version__ = "0.1.0"

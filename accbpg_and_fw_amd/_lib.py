@@ -42,6 +42,11 @@ _SIGS = {
     "accbpg_vec_axpby": (C.c_int, [C.c_double, _P, C.c_double, _P, C.c_int64, _P, _P]),
     "accbpg_vec_dot_diff": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double), _P, _P]),
     "accbpg_vec_min_sum": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_double), _P, _P]),
+    "accbpg_vec_div_scalar": (C.c_int, [_P, C.c_double, C.c_int64, _P, _P]),
+    "accbpg_vec_vertex": (C.c_int, [C.c_int64, C.c_double, C.c_double, C.c_int64, _P, _P]),
+    "accbpg_vec_argminmax": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double), _P, _P]),
+    "accbpg_dopt_vt_times": (C.c_int, [_P, _P, _P]),
+    "accbpg_dopt_get_column": (C.c_int, [_P, C.c_int64, _P]),
     "accbpg_fw_init": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),
     "accbpg_fw_probe_step": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FwProbe)]),
     "accbpg_fw_update": (C.c_int, [_P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double]),

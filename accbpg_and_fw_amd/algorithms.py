@@ -15,7 +15,7 @@ import time
 import numpy as np
 import torch
 
-from .functions import BurgEntropy, from_dev, ls_terms, to_dev, vec_axpby, vec_dot_diff
+from .functions import BurgEntropy, from_dev, ls_terms, to_dev, vec_axpby, vec_div_scalar, vec_dot_diff
 
 
 def _divergences(h, g, x, y, z, z_prev):
@@ -264,3 +264,149 @@ def ABPG_gain_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, G0=1,
 
     return (from_dev(x, as_numpy), F[0:k + 1], Gain[0:k + 1], Gdiv[0:k + 1],
             Gavg[0:k + 1], T[0:k + 1])
+
+
+def ABPG_expo(f, h, L, x0, gamma0, maxitrs, epsilon=1e-14, delta=0.2,
+              theta_eq=True, checkdiv=False, Gmargin=10, restart=False,
+              restart_rule='g', verbose=True, verbskip=1):
+    """Accelerated BPG with exponent adaption (accbpg/algorithms.py:183-292).
+    Returns (x, F, Gamma, G, T).  One gradient at y per outer iteration (:245); the inner loop
+    lowers gamma by delta while its test fails and gamma > 1 (:262-265); the restart test has no
+    k > 0 guard (:276-282)."""
+    return _drain(ABPG_expo_steps(f, h, L, x0, gamma0, maxitrs, epsilon, delta, theta_eq, checkdiv, Gmargin,
+                                  restart, restart_rule, verbose, verbskip))
+
+
+def ABPG_expo_steps(f, h, L, x0, gamma0, maxitrs, epsilon=1e-14, delta=0.2,
+                    theta_eq=True, checkdiv=False, Gmargin=10, restart=False,
+                    restart_rule='g', verbose=True, verbskip=1):
+    """Generator form of ABPG_expo: yields k after each outer iteration, returns its tuple."""
+    if verbose:
+        print("\nABPG_expo method for min_{x in C} F(x) = f(x) + Psi(x)")
+        print("     k      F(x)       theta       gamma" +
+              "        TSG       D(x+,y)     D(z+,z)     time")
+
+    t_start = time.time()
+    F = np.zeros(maxitrs)
+    G = np.zeros(maxitrs)
+    Gamma = np.ones(maxitrs) * gamma0
+    T = np.zeros(maxitrs)
+
+    gamma = gamma0
+    x, as_numpy = to_dev(x0)
+    x = x.clone()
+    z = x.clone()
+    theta = 1.0
+    kk = 0
+    k = -1
+    for k in range(maxitrs):
+        F[k] = f(x) + h.extra_Psi(x)                            # :231-232
+        T[k] = time.time() - t_start
+
+        z_prev, x_prev = z, x
+        if theta_eq and kk > 0:                                 # :238-241
+            theta = solve_theta(theta, gamma)
+        else:
+            theta = gamma / (kk + gamma)
+
+        y = vec_axpby(1 - theta, x_prev, theta, z_prev)         # :243
+        fy, g = f.func_grad(y)                                  # :245
+
+        trying = True
+        while trying:                                           # :248
+            z = h.div_prox_map(z_prev, g, theta ** (gamma - 1) * L)   # :249
+            x = vec_axpby(1 - theta, x_prev, theta, z)          # :250
+            lin, dxy, dzz = _divergences(h, g, x, y, z, z_prev)  # :253-254 and the dot of :260
+            Gdr = dxy / dzz / theta ** gamma                    # :255
+
+            if checkdiv:
+                trying = (dxy > Gmargin * (theta ** gamma) * dzz)    # :258
+            else:
+                trying = (f(x) > fy + lin + theta ** gamma * L * dzz)   # :260
+
+            if trying and gamma > 1:                            # :262-265
+                gamma = max(gamma - delta, 1)
+            else:
+                trying = False
+
+        G[k] = Gdr
+        Gamma[k] = gamma
+        if verbose and k % verbskip == 0:
+            print("{0:6d}  {1:10.3e}  {2:10.3e}  {3:10.3e}  {4:10.3e}  {5:10.3e}  {6:10.3e}  {7:6.1f}".format(
+                k, F[k], theta, gamma, Gdr, dxy, dzz, T[k]))
+
+        kk += 1
+        if restart:                                             # :276-282
+            if (restart_rule == 'f' and F[k] > F[k - 1]) or \
+               (restart_rule == 'g' and vec_dot_diff(g, x, x_prev) > 0):
+                theta = 1.0
+                kk = 0
+                z = x
+
+        if dzz < epsilon:                                       # :285
+            break
+        yield k
+
+    return from_dev(x, as_numpy), F[0:k + 1], Gamma[0:k + 1], G[0:k + 1], T[0:k + 1]
+
+
+def ABDA(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=True,
+         verbose=True, verbskip=1):
+    """Accelerated Bregman dual averaging (accbpg/algorithms.py:423-514).  Returns (x, F, G, T).
+    gavg accumulates theta^(1-gamma) * g (:483), z = prox_map(gavg/csum, L/csum) (:485)."""
+    return _drain(ABDA_steps(f, h, L, x0, gamma, maxitrs, epsilon, theta_eq, verbose, verbskip))
+
+
+def ABDA_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=True,
+               verbose=True, verbskip=1):
+    """Generator form of ABDA: yields k after each outer iteration, returns ABDA's tuple."""
+    if verbose:
+        print("\nABDA method for min_{x in C} F(x) = f(x) + Psi(x)")
+        print("     k      F(x)       theta" +
+              "        TSG       D(x+,y)     D(z+,z)     time")
+
+    t_start = time.time()
+    F = np.zeros(maxitrs)
+    G = np.zeros(maxitrs)
+    T = np.zeros(maxitrs)
+
+    x, as_numpy = to_dev(x0)
+    x = x.clone()
+    z = x.clone()
+    theta = 1.0
+    kk = 0
+    gavg = torch.zeros_like(x)
+    csum = 0
+    k = -1
+    for k in range(maxitrs):
+        F[k] = f(x) + h.extra_Psi(x)                            # :465-466
+        T[k] = time.time() - t_start
+
+        z_prev, x_prev = z, x
+        if theta_eq and kk > 0:                                 # :472-475
+            theta = solve_theta(theta, gamma)
+        else:
+            theta = gamma / (kk + gamma)
+
+        y = vec_axpby(1 - theta, x_prev, theta, z_prev)         # :477
+        g = f.gradient(y)                                       # :478
+        wgt = theta ** (1 - gamma)
+        gavg = vec_axpby(1.0, gavg, wgt, g)                     # :479  (1.0*gavg is exact)
+        csum = csum + wgt                                       # :480
+        z = h.prox_map(vec_div_scalar(gavg, csum), L / csum)    # :481
+        x = vec_axpby(1 - theta, x_prev, theta, z)              # :482
+
+        _, dxy, dzz = _divergences(h, None, x, y, z, z_prev)    # :485-486
+        Gdr = dxy / dzz / theta ** gamma
+
+        G[k] = Gdr
+        if verbose and k % verbskip == 0:
+            print("{0:6d}  {1:10.3e}  {2:10.3e}  {3:10.3e}  {4:10.3e}  {5:10.3e}  {6:6.1f}".format(
+                k, F[k], theta, Gdr, dxy, dzz, T[k]))
+
+        kk += 1
+        if dzz < epsilon:                                       # :508
+            break
+        yield k
+
+    return from_dev(x, as_numpy), F[0:k + 1], G[0:k + 1], T[0:k + 1]

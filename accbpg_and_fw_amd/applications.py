@@ -3,7 +3,59 @@ from __future__ import annotations
 
 import numpy as np
 
-from .functions import BurgEntropySimplex, DOptimalObj
+from .functions import BurgEntropySimplex, DOptimalObj, vec_argminmax
+from .utils import load_libsvm_file
+
+
+def D_opt_libsvm(filename):
+    """D-optimal design instance from a LIBSVM data file (accbpg/applications.py:17-33): the data
+    matrix, transposed when it has more rows than columns, is the m x n design matrix."""
+    X, y = load_libsvm_file(filename)
+    if X.shape[0] > X.shape[1]:
+        H = X.T.toarray('C')
+    else:
+        H = X.toarray('C')
+    n = H.shape[1]
+    f = DOptimalObj(H)
+    h = BurgEntropySimplex()
+    L = 1.0
+    x0 = (1.0 / n) * np.ones(n)
+    return f, h, L, x0
+
+
+def D_opt_KYinit(V):
+    """Sparse Kumar-Yildirim starting point (accbpg/applications.py:59-95).  ``V`` is the design
+    matrix or a DOptimalObj over it.  The m passes over V (q^T V, argmax / argmin, two column reads)
+    run on the GPU; the length-m Gram-Schmidt recurrences stay on the host in the reference's order
+    (coefficients from the un-deflated vector, :75-78 and :86-89), with the same legacy-RNG draws
+    (np.random.rand(m) per direction, :74)."""
+    obj = V if isinstance(V, DOptimalObj) else None
+    m, n = (obj.m, obj.n) if obj is not None else V.shape
+    if n <= 2 * m:
+        return (1.0 / n) * np.ones(n)
+    if obj is None:
+        obj = DOptimalObj(V)
+
+    picked = []
+    Q = np.zeros((m, m))
+    for i in range(m):
+        b = np.random.rand(m)
+        q = np.copy(b)
+        for j in range(i):
+            q = q - np.dot(Q[:, j], b) * Q[:, j]
+        kmin, kmax, _, _ = vec_argminmax(obj.vt_times(q))       # :79-81
+        picked.append(kmax)
+        picked.append(kmin)
+        v = obj.column(kmin) - obj.column(kmax)                 # :84
+        q = np.copy(v)
+        for j in range(i):
+            q = q - np.dot(Q[:, j], v) * Q[:, j]
+        Q[:, i] = q / np.linalg.norm(q)
+
+    x0 = np.zeros(n)
+    x0[picked] = np.ones(len(picked)) / len(picked)
+    x0 /= x0.sum()                                              # repeated indices: rescale to sum 1 (:93-94)
+    return x0
 
 
 def D_opt_design(m, n, randseed=-1):

@@ -187,6 +187,22 @@ __global__ __launch_bounds__(FB) void fw_wupdate_kernel(double* __restrict__ w, 
     }
 }
 
+// u = sum of the row-split partials (u = V^T q)
+__global__ __launch_bounds__(FB) void fw_usum_kernel(const double* __restrict__ upart, int nsplit, int64_t n,
+                                                    double* __restrict__ u) {
+    const int64_t stride = (int64_t)gridDim.x * FB;
+    for (int64_t k = (int64_t)blockIdx.x * FB + threadIdx.x; k < n; k += stride) {
+        double a = 0.0;
+        for (int s = 0; s < nsplit; ++s) a += upart[(int64_t)s * n + k];
+        u[k] = a;
+    }
+}
+__global__ __launch_bounds__(FB) void column_kernel(const double* __restrict__ V, int64_t ldv, int64_t m, int64_t j,
+                                                   double* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * FB;
+    for (int64_t r = (int64_t)blockIdx.x * FB + threadIdx.x; r < m; r += stride) out[r] = V[r * ldv + j];
+}
+
 // out = in^T for an m x m matrix (used once per fw_init to form H = W^T W on the MFMA engine)
 __global__ __launch_bounds__(FB) void transpose_kernel(const double* __restrict__ in, double* __restrict__ out,
                                                       int64_t m) {
@@ -328,5 +344,28 @@ extern "C" int accbpg_fw_get_state(accbpg_dopt* h, double* x_dev, double* w_dev,
     if (H_dev)
         ACC_HIP(hipMemcpyAsync(H_dev, h->fw_H, sizeof(double) * h->m * h->m, hipMemcpyDeviceToDevice, h->stream));
     ACC_HIP(hipStreamSynchronize(h->stream));
+    return ACCBPG_OK;
+}
+
+/* u = V^T q  (np.dot(q, V), applications.py:79): one pass over V on the split-row kernel */
+extern "C" int accbpg_dopt_vt_times(accbpg_dopt* h, const double* q_dev, double* u_dev) {
+    if (!h || !q_dev || !u_dev) return ACCBPG_ERR_ARG;
+    const int64_t m = h->m, n = h->n;
+    const int ns = fw_nsplit(h);
+    dim3 vg((unsigned)((n + VG_COLS - 1) / VG_COLS), (unsigned)ns);
+    fw_vgemv_partial_kernel<<<vg, FB, 0, h->stream>>>(h->V, h->ldv, m, n, q_dev, ns, h->vws, h->vec_ok);
+    int64_t wb = (n + FB - 1) / FB;
+    if (wb > 2048) wb = 2048;
+    fw_usum_kernel<<<(int)wb, FB, 0, h->stream>>>(h->vws, ns, n, u_dev);
+    ACC_HIP(hipGetLastError());
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_dopt_get_column(accbpg_dopt* h, int64_t j, double* out_dev) {
+    if (!h || !out_dev || j < 0 || j >= h->n) return ACCBPG_ERR_ARG;
+    int64_t gb = (h->m + FB - 1) / FB;
+    if (gb > 1024) gb = 1024;
+    column_kernel<<<(int)gb, FB, 0, h->stream>>>(h->V, h->ldv, h->m, j, out_dev);
+    ACC_HIP(hipGetLastError());
     return ACCBPG_OK;
 }

@@ -250,6 +250,70 @@ __global__ __launch_bounds__(RB) void axpby_kernel(double a, const double* __res
     }
 }
 
+// out = x / d elementwise (NumPy true division: gavg/csum, algorithms.py:485)
+__global__ __launch_bounds__(RB) void div_scalar_kernel(const double* __restrict__ x, double d, int64_t n,
+                                                       double* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * RB;
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) out[i] = x[i] / d;
+}
+
+// out[i] = fill, out[idx] = value  (lmo_simplex vertex, functions_lmo.py:152-157)
+__global__ __launch_bounds__(RB) void vertex_kernel(int64_t idx, double value, double fill, int64_t n,
+                                                   double* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * RB;
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) out[i] = (i == idx) ? value : fill;
+}
+
+struct MinMaxRec {
+    double vmin, vmax;
+    int64_t imin, imax;
+};
+__device__ __forceinline__ MinMaxRec mm_merge(MinMaxRec a, MinMaxRec b) {
+    MinMaxRec r = a;
+    if (b.vmin < a.vmin || (b.vmin == a.vmin && b.imin < a.imin)) { r.vmin = b.vmin; r.imin = b.imin; }
+    if (b.vmax > a.vmax || (b.vmax == a.vmax && b.imax < a.imax)) { r.vmax = b.vmax; r.imax = b.imax; }
+    return r;
+}
+__device__ __forceinline__ MinMaxRec mm_block(MinMaxRec a, MinMaxRec* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        MinMaxRec o;
+        o.vmin = __shfl_down(a.vmin, off); o.vmax = __shfl_down(a.vmax, off);
+        o.imin = __shfl_down((long long)a.imin, off); o.imax = __shfl_down((long long)a.imax, off);
+        a = mm_merge(a, o);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = a;
+    __syncthreads();
+    MinMaxRec r = sh[0];
+    for (int i = 1; i < RB / 64; ++i) r = mm_merge(r, sh[i]);
+    return r;
+}
+// first-index argmin and argmax (np.argmin / np.argmax / np.where(g == g.min())[0][0])
+__global__ __launch_bounds__(RB) void minmax_partial_kernel(const double* __restrict__ x, int64_t n,
+                                                           MinMaxRec* __restrict__ part) {
+    __shared__ MinMaxRec sh[RB / 64];
+    const double inf = __builtin_inf();
+    MinMaxRec a{inf, -inf, INT64_MAX, INT64_MAX};
+    const int64_t stride = (int64_t)gridDim.x * RB;
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
+        const double v = x[i];
+        a = mm_merge(a, MinMaxRec{v, v, i, i});
+    }
+    a = mm_block(a, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+__global__ __launch_bounds__(RB) void minmax_final_kernel(const MinMaxRec* __restrict__ part, int nblk,
+                                                         MinMaxRec* __restrict__ out) {
+    __shared__ MinMaxRec sh[RB / 64];
+    const double inf = __builtin_inf();
+    MinMaxRec a{inf, -inf, INT64_MAX, INT64_MAX};
+    for (int b = threadIdx.x; b < nblk; b += RB) a = mm_merge(a, part[b]);
+    a = mm_block(a, sh);
+    if (threadIdx.x == 0) *out = a;
+}
+
 // -----------------------------------------------------------------------------------------
 // per host thread (instances of a batch are driven from separate threads on separate streams)
 static thread_local double* g_pin = nullptr;       // pinned host scratch (32 doubles)
@@ -374,5 +438,44 @@ extern "C" int accbpg_vec_axpby(double a, const double* x_dev, double b, const d
     if (nb > 2048) nb = 2048;
     axpby_kernel<<<(int)nb, RB, 0, s>>>(a, x_dev, b, z_dev, n, out_dev);
     ACC_HIP(hipGetLastError());
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_vec_div_scalar(const double* x_dev, double d, int64_t n, double* out_dev, void* stream) {
+    if (!x_dev || !out_dev || n <= 0) return ACCBPG_ERR_ARG;
+    int64_t nb = (n + RB - 1) / RB;
+    if (nb > 2048) nb = 2048;
+    div_scalar_kernel<<<(int)nb, RB, 0, (hipStream_t)stream>>>(x_dev, d, n, out_dev);
+    ACC_HIP(hipGetLastError());
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_vec_vertex(int64_t idx, double value, double fill, int64_t n, double* out_dev, void* stream) {
+    if (!out_dev || n <= 0 || idx < 0 || idx >= n) return ACCBPG_ERR_ARG;
+    int64_t nb = (n + RB - 1) / RB;
+    if (nb > 2048) nb = 2048;
+    vertex_kernel<<<(int)nb, RB, 0, (hipStream_t)stream>>>(idx, value, fill, n, out_dev);
+    ACC_HIP(hipGetLastError());
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_vec_argminmax(const double* x_dev, int64_t n, int64_t* idx_host, double* val_host,
+                                    double* ws_dev, void* stream) {
+    if (!x_dev || n <= 0 || !idx_host || !ws_dev) return ACCBPG_ERR_ARG;
+    ACC_TRY(ensure_scratch());
+    hipStream_t s = (hipStream_t)stream;
+    int nb = red_blocks(n);
+    if (nb > 128) nb = 128;                                     // 128 records of 32 B = the 4096-double tail of ws
+    MinMaxRec* part = reinterpret_cast<MinMaxRec*>(ws_dev + n + (n & 1));
+    MinMaxRec* out = reinterpret_cast<MinMaxRec*>(g_out + 8);
+    minmax_partial_kernel<<<nb, RB, 0, s>>>(x_dev, n, part);
+    minmax_final_kernel<<<1, RB, 0, s>>>(part, nb, out);
+    ACC_HIP(hipGetLastError());
+    ACC_HIP(hipMemcpyAsync(g_pin + 16, out, sizeof(MinMaxRec), hipMemcpyDeviceToHost, s));
+    ACC_HIP(hipStreamSynchronize(s));
+    const MinMaxRec* r = reinterpret_cast<const MinMaxRec*>(g_pin + 16);
+    idx_host[0] = r->imin;
+    idx_host[1] = r->imax;
+    if (val_host) { val_host[0] = r->vmin; val_host[1] = r->vmax; }
     return ACCBPG_OK;
 }

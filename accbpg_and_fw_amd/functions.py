@@ -165,6 +165,25 @@ class DOptimalObj(RSmoothFunction):
             rc = self._lib.accbpg_dopt_grad(self._h, _ptr(g_dev))
         _lib.check(rc, "accbpg_dopt_grad")
 
+    # ---- pieces used by D_opt_KYinit (accbpg/applications.py:79,84) ----
+    def vt_times(self, q):
+        """u = V^T q (np.dot(q, V)) for a length-m vector q -> length-n device vector."""
+        qd, _ = to_dev(q)
+        u = torch.empty(self.n, dtype=torch.float64, device=self._V.device)
+        with torch.cuda.device(self._V.device):
+            self._lib.accbpg_dopt_set_stream(self._h, _stream())
+            rc = self._lib.accbpg_dopt_vt_times(self._h, _ptr(qd), _ptr(u))
+        _lib.check(rc, "accbpg_dopt_vt_times")
+        return u
+
+    def column(self, j):
+        """V[:, j] as a NumPy vector."""
+        out = torch.empty(self.m, dtype=torch.float64, device=self._V.device)
+        with torch.cuda.device(self._V.device):
+            rc = self._lib.accbpg_dopt_get_column(self._h, int(j), _ptr(out))
+        _lib.check(rc, "accbpg_dopt_get_column")
+        return out.cpu().numpy()
+
     # ---- kernel-time accounting used by bench.py ----
     def profile(self, enable=True):
         self._lib.accbpg_dopt_profile_enable(self._h, 1 if enable else 0)
@@ -317,3 +336,31 @@ def vec_min_sum(x):
         rc = _lib.load().accbpg_vec_min_sum(_ptr(x), x.numel(), out, _ptr(ws), _stream())
     _lib.check(rc, "accbpg_vec_min_sum")
     return out[0], out[1]
+
+
+def vec_div_scalar(x, d):
+    """x / d elementwise (NumPy true division)."""
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = _lib.load().accbpg_vec_div_scalar(_ptr(x), float(d), x.numel(), _ptr(out), _stream())
+    _lib.check(rc, "accbpg_vec_div_scalar")
+    return out
+
+
+def vec_argminmax(x):
+    """(first argmin, first argmax, min, max) of a device vector."""
+    idx = (C.c_int64 * 2)(0, 0)
+    val = (C.c_double * 2)(0.0, 0.0)
+    with torch.cuda.device(x.device):
+        ws = _Workspace.get(x.numel(), x.device)
+        rc = _lib.load().accbpg_vec_argminmax(_ptr(x), x.numel(), idx, val, _ptr(ws), _stream())
+    _lib.check(rc, "accbpg_vec_argminmax")
+    return idx[0], idx[1], val[0], val[1]
+
+
+def vec_vertex(idx, value, fill, n, device):
+    out = torch.empty(n, dtype=torch.float64, device=device)
+    with torch.cuda.device(device):
+        rc = _lib.load().accbpg_vec_vertex(int(idx), float(value), float(fill), int(n), _ptr(out), _stream())
+    _lib.check(rc, "accbpg_vec_vertex")
+    return out

@@ -108,6 +108,27 @@ int accbpg_vec_dot_diff(const double* g_dev, const double* x_dev, const double* 
 /* out_host = { min(x), sum(x) } -- precondition checks and diagnostics. */
 int accbpg_vec_min_sum(const double* x_dev, int64_t n, double* out_host, double* ws_dev, void* stream);
 
+/* ---- callers either side of the path ------------------------------------- */
+
+/* out <- x / d, NumPy true division (gavg/csum of ABDA, accbpg/algorithms.py:485) */
+int accbpg_vec_div_scalar(const double* x_dev, double d, int64_t n, double* out_dev, void* stream);
+
+/* out[i] <- fill, out[idx] <- value: the simplex vertex returned by lmo_simplex
+ * (accbpg/functions_lmo.py:152-157: 1e-15 everywhere, radius at the first argmin of g). */
+int accbpg_vec_vertex(int64_t idx, double value, double fill, int64_t n, double* out_dev, void* stream);
+
+/* idx_host = {first argmin, first argmax} of x, val_host (optional) = {min, max}
+ * (np.argmin / np.argmax, accbpg/applications.py:80-81; np.where(g == g.min())[0][0],
+ * functions_lmo.py:155-156). */
+int accbpg_vec_argminmax(const double* x_dev, int64_t n, int64_t* idx_host, double* val_host,
+                         double* ws_dev, void* stream);
+
+/* u <- V^T q (length n) for a length-m q: np.dot(q, V) of D_opt_KYinit (accbpg/applications.py:79). */
+int accbpg_dopt_vt_times(accbpg_dopt* h, const double* q_dev, double* u_dev);
+
+/* out <- V[:, j] (length m): the column reads of D_opt_KYinit (accbpg/applications.py:84). */
+int accbpg_dopt_get_column(accbpg_dopt* h, int64_t j, double* out_dev);
+
 /* ---- Frank-Wolfe / Wolfe-Atwood state: replaces the bodies of D_opt_FW and --------------
  * D_opt_FW_away (accbpg/D_opt_alg.py:9-88, 91-185).  State (x, inverse H = (V X V^T)^-1,
  * w_i = v_i^T H v_i) lives in the handle. */

@@ -166,18 +166,63 @@ def large(accbpg, m=2048, n=32768, seed=10, iters=12):
          away_x=xa, away_F=Fa, away_SP=SPa, away_SN=SNa)
 
 
+def next_rows(accbpg):
+    """KYinit / libsvm instances, ABPG_expo, ABDA, FW_alg_div_step + lmo_simplex,
+    with the calls of frank_wolfe_wtih_rs/ex_Dopt_design.py:12-21 on the housing instance and of
+    ipynb/ex_Dopt_random.ipynb on the (80,200) instance."""
+    import numpy as np
+    out = {}
+    for name in ["housing", "bodyfat", "mpg", "abalone"]:
+        f, h, L, x0 = accbpg.D_opt_libsvm(os.path.join(REF, "parameters_free_fw", "data", name + ".txt"))
+        out["libsvm_%s_shape" % name] = np.array(f.H.shape)
+        out["libsvm_%s_f0" % name] = f(x0)
+        out["libsvm_%s_checksum" % name] = np.array([f.H.sum(), np.abs(f.H).max(), (f.H ** 2).sum()])
+    f, h, L, x0 = accbpg.D_opt_libsvm(os.path.join(REF, "parameters_free_fw", "data", "housing.txt"))
+    x, F, Ls, T = accbpg.BPG(f, h, L, x0, maxitrs=300, linesearch=True, ls_ratio=2, verbose=False)
+    out.update(h_bpg_x=x, h_bpg_F=F, h_bpg_Ls=Ls)
+    x, F, Ls, T = accbpg.FW_alg_div_step(f, h, L, x0, lmo=accbpg.lmo_simplex(), maxitrs=300, gamma=2.0,
+                                         ls_ratio=2, verbose=False)
+    out.update(h_fwdiv_x=x, h_fwdiv_F=F, h_fwdiv_Ls=Ls)
+    x, F, Gamma, G, T = accbpg.ABPG_expo(f, h, L, x0, gamma0=3, maxitrs=300, theta_eq=True, Gmargin=100,
+                                         verbose=False)
+    out.update(h_expo_x=x, h_expo_F=F, h_expo_Gamma=Gamma, h_expo_G=G)
+    f, h, L, x0 = accbpg.D_opt_design(80, 200, randseed=10)
+    x, F, Gamma, G, T = accbpg.ABPG_expo(f, h, L, x0, gamma0=3, maxitrs=300, theta_eq=True, verbose=False)
+    out.update(r_expo_x=x, r_expo_F=F, r_expo_Gamma=Gamma, r_expo_G=G)
+    x, F, Gamma, G, T = accbpg.ABPG_expo(f, h, L, x0, gamma0=2.5, maxitrs=200, theta_eq=False, checkdiv=True,
+                                         Gmargin=5, restart=True, verbose=False)
+    out.update(r_expo2_x=x, r_expo2_F=F, r_expo2_Gamma=Gamma, r_expo2_G=G)
+    x, F, G, T = accbpg.ABDA(f, h, L, x0, gamma=2, maxitrs=300, theta_eq=True, verbose=False)
+    out.update(r_abda_x=x, r_abda_F=F, r_abda_G=G)
+    x, F, Ls, T = accbpg.FW_alg_div_step(f, h, L, x0, lmo=accbpg.lmo_simplex(), maxitrs=300, gamma=2.0,
+                                         ls_ratio=2, verbose=False)
+    out.update(r_fwdiv_x=x, r_fwdiv_F=F, r_fwdiv_Ls=Ls)
+    # Kumar-Yildirim start (ipynb/ABPGvsFW/ex_Dopt_ABPGvsFW.ipynb:171-173 uses D_opt_design(30,1000))
+    f, h, L, x0 = accbpg.D_opt_design(30, 1000, randseed=4)
+    np.random.seed(99)
+    xky = accbpg.D_opt_KYinit(f.H)
+    out.update(ky_x=xky, ky_f=f(np.maximum(xky, 0)) if xky.min() >= 0 else np.nan)
+    xs, F, SP, SN, T = accbpg.D_opt_FW_away(f.H, xky, 1e-8, 2000, verbose=False)
+    out.update(ky_away_x=xs, ky_away_F=F, ky_away_SP=SP, ky_away_SN=SN)
+    save("next_rows", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--medium", action="store_true")
     ap.add_argument("--large", action="store_true")
     ap.add_argument("--only-large", action="store_true")
     ap.add_argument("--only-traces", action="store_true")
+    ap.add_argument("--only-next", action="store_true")
     ap.add_argument("--out", default=None, help="write into this directory instead of tests/golden")
     args = ap.parse_args()
     accbpg = load_reference()
     if args.out:
         global OUT
         OUT = args.out
+    if args.only_next:
+        next_rows(accbpg)
+        return
     if args.only_traces:
         solver_traces(accbpg, "80x200", 80, 200, 10, 1000)
         solver_traces(accbpg, "80x120", 80, 120, 10, 300)
@@ -193,6 +238,7 @@ def main():
         fw_traces(accbpg, "30x1000", 30, 1000, 5, 6000)
         fw_traces(accbpg, "64x512", 64, 512, 2, 3000)
         housing(accbpg)
+        next_rows(accbpg)
     if args.medium:
         percall(accbpg, "512x8192", 512, 8192, 1)
         solver_traces(accbpg, "256x4096", 256, 4096, 10, 1000)

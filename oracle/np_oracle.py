@@ -389,3 +389,209 @@ def D_opt_FW_away(V, x0, eps, maxitrs, verbose=False, verbskip=1):
             H = (H + coef * np.outer(Hv, Hv)) / (1 + t)
             w = (w + coef * np.dot(Hv, V) ** 2) / (1 + t)
     return x, F[:k + 1], SP[:k + 1], SN[:k + 1], T[:k + 1]
+
+
+# ==========================================================================
+# callers and data formats either side of the path
+# ==========================================================================
+def ABPG_expo(f, h, L, x0, gamma0, maxitrs, epsilon=1e-14, delta=0.2, theta_eq=True,
+              checkdiv=False, Gmargin=10, restart=False, restart_rule='g', verbose=False, verbskip=1):
+    """Exponent-adaptive ABPG (algorithms.py:183-292): the gradient at y is taken once per outer
+    iteration (:245); the inner loop lowers gamma by delta while the test fails and gamma > 1
+    (:262-265); restart has no k > 0 guard (:276-282)."""
+    t0 = time.time()
+    F = np.zeros(maxitrs); G = np.zeros(maxitrs)
+    Gamma = np.ones(maxitrs) * gamma0; T = np.zeros(maxitrs)
+    gamma = gamma0
+    x = np.copy(x0); z = np.copy(x0)
+    theta, kk = 1.0, 0
+    k = -1
+    for k in range(maxitrs):
+        F[k] = f(x) + h.extra_Psi(x)
+        T[k] = time.time() - t0
+        z_prev, x_prev = z, x
+        theta = solve_theta(theta, gamma) if (theta_eq and kk > 0) else gamma / (kk + gamma)
+        y = (1 - theta) * x_prev + theta * z_prev
+        fy, g = f.func_grad(y)
+        again = True
+        while again:
+            z = h.div_prox_map(z_prev, g, theta ** (gamma - 1) * L)
+            x = (1 - theta) * x_prev + theta * z
+            dxy = h.divergence(x, y)
+            dzz = h.divergence(z, z_prev)
+            Gdr = dxy / dzz / theta ** gamma
+            if checkdiv:
+                again = (dxy > Gmargin * (theta ** gamma) * dzz)
+            else:
+                again = (f(x) > fy + np.dot(g, x - y) + theta ** gamma * L * dzz)
+            if again and gamma > 1:
+                gamma = max(gamma - delta, 1)
+            else:
+                again = False
+        G[k] = Gdr
+        Gamma[k] = gamma
+        kk += 1
+        if restart:
+            if (restart_rule == 'f' and F[k] > F[k - 1]) or \
+               (restart_rule == 'g' and np.dot(g, x - x_prev) > 0):
+                theta, kk, z = 1.0, 0, x
+        if dzz < epsilon:
+            break
+    return x, F[:k + 1], Gamma[:k + 1], G[:k + 1], T[:k + 1]
+
+
+def ABDA(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=True, verbose=False, verbskip=1):
+    """Accelerated Bregman dual averaging (algorithms.py:423-514): weighted gradient average
+    gavg += theta^(1-gamma) g (:483), z = prox_map(gavg/csum, L/csum) (:485)."""
+    t0 = time.time()
+    F = np.zeros(maxitrs); G = np.zeros(maxitrs); T = np.zeros(maxitrs)
+    x = np.copy(x0); z = np.copy(x0)
+    theta, kk = 1.0, 0
+    gavg = np.zeros(x.size)
+    csum = 0
+    k = -1
+    for k in range(maxitrs):
+        F[k] = f(x) + h.extra_Psi(x)
+        T[k] = time.time() - t0
+        z_prev, x_prev = z, x
+        theta = solve_theta(theta, gamma) if (theta_eq and kk > 0) else gamma / (kk + gamma)
+        y = (1 - theta) * x_prev + theta * z_prev
+        g = f.gradient(y)
+        gavg = gavg + theta ** (1 - gamma) * g
+        csum = csum + theta ** (1 - gamma)
+        z = h.prox_map(gavg / csum, L / csum)
+        x = (1 - theta) * x_prev + theta * z
+        dxy = h.divergence(x, y)
+        dzz = h.divergence(z, z_prev)
+        G[k] = dxy / dzz / theta ** gamma
+        kk += 1
+        if dzz < epsilon:
+            break
+    return x, F[:k + 1], G[:k + 1], T[:k + 1]
+
+
+def lmo_simplex(radius=1):
+    """Simplex LMO (functions_lmo.py:137-160): 1e-15 everywhere, `radius` at the first argmin."""
+    def vertex(g):
+        s = np.zeros(g.shape)
+        s += 1e-15
+        s[np.where(g == np.min(g))[0][0]] = radius
+        return s
+    return vertex
+
+
+def FW_alg_div_step(f, h, L, x0, maxitrs, gamma, lmo, epsilon=1e-14, linesearch=True, ls_ratio=2,
+                    verbose=False, verbskip=1):
+    """Frank-Wolfe with a Bregman step size (algorithms_fw.py:6-75)."""
+    if ls_ratio < 1:
+        raise ValueError("ls_ratio must be >= 1")
+    if L <= 0:
+        raise ValueError("Initial L must be positive")
+    if epsilon <= 0:
+        raise ValueError("epsilon must be positive")
+    t0 = time.time()
+    F, Ls, T = [], [], []
+    tiny = 1e-6
+    x = np.copy(x0)
+    for k in range(maxitrs):
+        fx, g = f.func_grad(x)
+        F.append(fx + h.extra_Psi(x))
+        T.append(time.time() - t0)
+        s = lmo(g)
+        d = s - x
+        div = h.divergence(s, x)
+        if div == 0:
+            div = tiny
+        slope = np.dot(g.ravel(), d.ravel())
+        if 0 < slope <= tiny:
+            slope = 0.0
+        if slope > 0:
+            raise ValueError("grad_d_prod must be non-positive")
+        if linesearch:
+            L = L / ls_ratio
+        while True:
+            alpha = min((-slope / (2 * L * div)) ** (1 / (gamma - 1)), 1.0)
+            x1 = x + alpha * d
+            if not linesearch:
+                break
+            assert not math.isinf(L), "L is infinite"
+            if f.func_grad(x1, flag=0) <= fx + alpha * slope + alpha ** gamma * L * div:
+                break
+            L = L * ls_ratio
+        x = x1
+        Ls.append(L)
+        if k > 0 and abs(F[k] - F[k - 1]) < epsilon:
+            break
+    return x, np.array(F), np.array(Ls), np.array(T)
+
+
+def D_opt_KYinit(V):
+    """Kumar-Yildirim sparse starting point (applications.py:59-95).  Uses the legacy global RNG
+    (np.random.rand(m) per direction) and a Gram-Schmidt whose coefficients come from the
+    un-deflated vector (:75-78, :86-89)."""
+    m, n = V.shape
+    if n <= 2 * m:
+        return (1.0 / n) * np.ones(n)
+    picked = []
+    Q = np.zeros((m, m))
+    for i in range(m):
+        b = np.random.rand(m)
+        q = np.copy(b)
+        for j in range(i):
+            q = q - np.dot(Q[:, j], b) * Q[:, j]
+        proj = np.dot(q, V)
+        kmax = np.argmax(proj)
+        kmin = np.argmin(proj)
+        picked.append(kmax)
+        picked.append(kmin)
+        v = V[:, kmin] - V[:, kmax]
+        q = np.copy(v)
+        for j in range(i):
+            q = q - np.dot(Q[:, j], v) * Q[:, j]
+        Q[:, i] = q / np.linalg.norm(q)
+    x0 = np.zeros(n)
+    x0[picked] = np.ones(len(picked)) / len(picked)
+    x0 /= x0.sum()
+    return x0
+
+
+def load_libsvm_file(filename):
+    """LIBSVM text -> (dense samples x features array, labels); index base detected as in
+    utils.py:22-95 (indices shifted down when the smallest one is > 0)."""
+    labels, rows = [], []
+    with open(filename, "r") as fh:
+        for line in fh:
+            cut = line.find('#')
+            if cut >= 0:
+                line = line[:cut]
+            parts = line.split()
+            if not parts:
+                continue
+            labels.append(float(parts[0]))
+            entry, prev = [], -1
+            for tok in parts[1:]:
+                idx_s, val = tok.split(':', 1)
+                idx = int(idx_s)
+                if idx < 0:
+                    raise ValueError("Invalid index {0:d} in LibSVM data file.".format(idx))
+                if idx <= prev:
+                    raise ValueError("Feature indices in LibSVM data fileshould be sorted and unique.")
+                entry.append((idx, float(val)))
+                prev = idx
+            rows.append(entry)
+    all_idx = [i for r in rows for i, _ in r]
+    shift = 1 if min(all_idx) > 0 else 0
+    nfeat = max(all_idx) - shift + 1
+    X = np.zeros((len(rows), nfeat))
+    for r, entry in enumerate(rows):
+        for i, v in entry:
+            X[r, i - shift] = v
+    return X, np.array(labels)
+
+
+def D_opt_libsvm(filename):
+    """applications.py:17-33: design matrix = the data matrix, transposed if it is tall."""
+    X, y = load_libsvm_file(filename)
+    H = np.ascontiguousarray(X.T) if X.shape[0] > X.shape[1] else np.ascontiguousarray(X)
+    n = H.shape[1]
+    return DOptOracle(H), BurgSimplexOracle(), 1.0, (1.0 / n) * np.ones(n)

@@ -90,3 +90,43 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "np_oracle" not in text and "from oracle" not in text and "import oracle" not in text, fn
+
+
+def test_libsvm_loader_cpu():
+    """load_libsvm_file (accbpg/utils.py:22-95) is host code: CSR result, index-base detection,
+    comments, error cases; matrices equal the oracle's and the reference's checksums."""
+    import numpy as np
+    import accbpg_and_fw_amd as acc
+    from oracle import np_oracle as O
+    gd = np.load(os.path.join(ROOT, "tests", "golden", "next_rows.npz"))
+    for name in ["housing", "bodyfat", "mpg", "abalone"]:
+        path = os.path.join(ROOT, "tests", "golden", "data", name + ".txt")
+        X, y = acc.load_libsvm_file(path)
+        Xo, yo = O.load_libsvm_file(path)
+        np.testing.assert_array_equal(X.toarray(), Xo)
+        np.testing.assert_array_equal(y, yo)
+        H = X.T.toarray('C') if X.shape[0] > X.shape[1] else X.toarray('C')
+        assert tuple(gd["libsvm_%s_shape" % name]) == H.shape
+        np.testing.assert_allclose([H.sum(), np.abs(H).max(), (H ** 2).sum()], gd["libsvm_%s_checksum" % name],
+                                   rtol=1e-14)
+
+
+def test_libsvm_loader_edge_cases(tmp_path):
+    import numpy as np
+    import accbpg_and_fw_amd as acc
+    p = tmp_path / "a.txt"
+    p.write_text("1 1:0.5 3:2 # comment\n\n# whole-line comment\n-1 2:1.5\n")
+    X, y = acc.load_libsvm_file(str(p))
+    np.testing.assert_array_equal(X.toarray(), [[0.5, 0, 2.0], [0, 1.5, 0]])
+    np.testing.assert_array_equal(y, [1.0, -1.0])
+    p.write_text("1 0:0.5 2:2\n")                       # zero-based file: no shift
+    X, y = acc.load_libsvm_file(str(p))
+    assert X.shape == (1, 3) and X[0, 0] == 0.5
+    X, y = acc.load_libsvm_file(str(p), n_features=5)
+    assert X.shape == (1, 5)
+    p.write_text("1 2:1 2:3\n")
+    with pytest.raises(ValueError):
+        acc.load_libsvm_file(str(p))
+    p.write_text("1 -1:1\n")
+    with pytest.raises(ValueError):
+        acc.load_libsvm_file(str(p))

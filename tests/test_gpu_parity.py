@@ -451,3 +451,89 @@ def test_batched_instances_match_sequential(acc):
         np.testing.assert_array_equal(a[0], b[0])          # same kernels, same order per instance -> bitwise
         np.testing.assert_array_equal(a[1], b[1])
         np.testing.assert_array_equal(a[2], b[2])
+
+
+# ------------------------------------------------------------------ SURVEY 8(f) rows 1-3
+import os as _os
+_DATA = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "data")
+
+
+def test_libsvm_instances_gpu(acc):
+    """D_opt_libsvm on the four vendored files: F(x0) as the reference computes it."""
+    gd = golden("next_rows")
+    for name in ["housing", "bodyfat", "mpg", "abalone"]:
+        f, h, L, x0 = acc.D_opt_libsvm(_os.path.join(_DATA, name + ".txt"))
+        assert f.H.shape == tuple(gd["libsvm_%s_shape" % name])
+        assert f(x0) == pytest.approx(float(gd["libsvm_%s_f0" % name]), rel=1e-11)
+
+
+def test_expo_abda_fwdiv_trajectories(acc):
+    """ABPG_expo, ABDA and FW_alg_div_step + lmo_simplex with the calls of
+    frank_wolfe_wtih_rs/ex_Dopt_design.py:12-21 (housing) and on D_opt_design(80,200,seed 10)."""
+    gd = golden("next_rows")
+    f, h, L, x0 = acc.D_opt_libsvm(_os.path.join(_DATA, "housing.txt"))
+    x, F, Ls, T = acc.BPG(f, h, L, x0, maxitrs=300, linesearch=True, ls_ratio=2, verbose=False)
+    _close(F, gd["h_bpg_F"], 1e-9); _close(Ls, gd["h_bpg_Ls"], 1e-12)
+    x, F, Ls, T = acc.FW_alg_div_step(f, h, L, x0, lmo=acc.lmo_simplex(), maxitrs=300, gamma=2.0, ls_ratio=2,
+                                      verbose=False)
+    k = _agree_prefix(Ls, gd["h_fwdiv_Ls"], 1e-12)
+    assert k >= 150, k
+    _close(F[:k], gd["h_fwdiv_F"][:k], 1e-9)
+    x, F, Gamma, G, T = acc.ABPG_expo(f, h, L, x0, gamma0=3, maxitrs=300, theta_eq=True, Gmargin=100, verbose=False)
+    k = _agree_prefix(Gamma, gd["h_expo_Gamma"], 1e-12)
+    assert k >= 100, k
+    _close(F[:100], gd["h_expo_F"][:100], 1e-9)
+    f, h, L, x0 = acc.D_opt_design(80, 200, randseed=10)
+    x, F, Gamma, G, T = acc.ABPG_expo(f, h, L, x0, gamma0=3, maxitrs=300, theta_eq=True, verbose=False)
+    k = _agree_prefix(Gamma, gd["r_expo_Gamma"], 1e-12)
+    assert k >= 200, k
+    _close(F[:200], gd["r_expo_F"][:200], 1e-9)
+    assert len(F) == len(Gamma) == len(G) == len(T)
+    x, F, Gamma, G, T = acc.ABPG_expo(f, h, L, x0, gamma0=2.5, maxitrs=200, theta_eq=False, checkdiv=True,
+                                      Gmargin=5, restart=True, verbose=False)
+    k = _agree_prefix(Gamma, gd["r_expo2_Gamma"], 1e-12)
+    assert k >= 40, k
+    _close(F[:40], gd["r_expo2_F"][:40], 1e-9)
+    x, F, G, T = acc.ABDA(f, h, L, x0, gamma=2, maxitrs=300, theta_eq=True, verbose=False)
+    _close(F, gd["r_abda_F"], 1e-9)
+    assert np.max(np.abs(x - gd["r_abda_x"])) < 1e-9
+    x, F, Ls, T = acc.FW_alg_div_step(f, h, L, x0, lmo=acc.lmo_simplex(), maxitrs=300, gamma=2.0, ls_ratio=2,
+                                      verbose=False)
+    k = _agree_prefix(Ls, gd["r_fwdiv_Ls"], 1e-12)
+    assert k >= 150, k
+    _close(F[:k], gd["r_fwdiv_F"][:k], 1e-9)
+    with pytest.raises(ValueError):
+        acc.FW_alg_div_step(f, h, -1.0, x0, 5, 2.0, acc.lmo_simplex(), verbose=False)
+
+
+def test_lmo_simplex_and_argminmax(acc):
+    from accbpg_and_fw_amd.functions import vec_argminmax, vec_div_scalar
+    rng = np.random.RandomState(8)
+    for n in [5, 1000, 70001]:
+        g = rng.randn(n)
+        g[rng.randint(n)] = g.min()                 # a tie: the first index must win
+        s = acc.lmo_simplex(2.0)(g)
+        ref = np.zeros(n) + 1e-15
+        ref[np.where(g == g.min())[0][0]] = 2.0
+        np.testing.assert_array_equal(s, ref)
+        imin, imax, vmin, vmax = vec_argminmax(dev(g))
+        assert imin == np.argmin(g) and imax == np.argmax(g) and vmin == g.min() and vmax == g.max()
+        np.testing.assert_array_equal(vec_div_scalar(dev(g), 3.7).cpu().numpy(), g / 3.7)
+
+
+def test_kyinit_gpu(acc):
+    """Kumar-Yildirim start: identical support and weights to the reference for the same RNG state,
+    and FW-away started from it follows the reference's trajectory."""
+    gd = golden("next_rows")
+    f, h, L, x0 = acc.D_opt_design(30, 1000, randseed=4)
+    np.random.seed(99)
+    xky = acc.D_opt_KYinit(f.H)
+    np.testing.assert_array_equal(xky, gd["ky_x"])
+    np.random.seed(99)
+    np.testing.assert_array_equal(acc.D_opt_KYinit(f), gd["ky_x"])        # also accepts the objective
+    np.testing.assert_array_equal(acc.D_opt_KYinit(np.zeros((30, 60))), np.ones(60) / 60)
+    xs, F, SP, SN, T = acc.D_opt_FW_away(f.H, xky, 1e-8, 2000, verbose=False)
+    k = min(len(F), len(gd["ky_away_F"]))
+    assert abs(len(F) - len(gd["ky_away_F"])) <= 2
+    _close(F[:k], gd["ky_away_F"][:k], 1e-8)
+    assert np.max(np.abs(xs - gd["ky_away_x"])) < 1e-8

@@ -145,3 +145,59 @@ def test_solve_theta_and_asserts():
         h.div_prox_map(x0, x0, -1.0)
     with pytest.raises(AssertionError):
         h.divergence(x0, 0 * x0)
+
+
+# ------------------------------------------------------------------ SURVEY 8(f) rows 1-3
+DATA = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "data")
+
+
+def test_libsvm_instances_match_reference():
+    """F(x0) of the four vendored LIBSVM files (-4.136876e+01, -3.474969e+01,
+    -3.416310e+01, 3.978055e+01) and the parsed matrices' checksums."""
+    gd = golden("next_rows")
+    expect = {"housing": "-4.136876e+01", "bodyfat": "-3.474969e+01", "mpg": "-3.416310e+01", "abalone": "3.978055e+01"}
+    for name, txt in expect.items():
+        f, h, L, x0 = O.D_opt_libsvm(__import__("os").path.join(DATA, name + ".txt"))
+        assert tuple(gd["libsvm_%s_shape" % name]) == f.H.shape
+        np.testing.assert_allclose([f.H.sum(), np.abs(f.H).max(), (f.H ** 2).sum()],
+                                   gd["libsvm_%s_checksum" % name], rtol=1e-14)
+        f0 = f(x0)
+        assert f0 == pytest.approx(float(gd["libsvm_%s_f0" % name]), rel=1e-13)
+        assert "%.6e" % f0 == txt
+
+
+def test_next_row_solvers_match_reference():
+    gd = golden("next_rows")
+    f, h, L, x0 = O.D_opt_libsvm(__import__("os").path.join(DATA, "housing.txt"))
+    x, F, Ls, T = O.FW_alg_div_step(f, h, L, x0, lmo=O.lmo_simplex(), maxitrs=300, gamma=2.0, ls_ratio=2)
+    _check(F, gd["h_fwdiv_F"], 1e-11); _check(Ls, gd["h_fwdiv_Ls"], 1e-12); _check(x, gd["h_fwdiv_x"], 1e-11)
+    x, F, Gamma, G, T = O.ABPG_expo(f, h, L, x0, gamma0=3, maxitrs=300, theta_eq=True, Gmargin=100)
+    k = _prefix(Gamma, gd["h_expo_Gamma"], 1e-12)
+    assert k >= 100
+    _check(F[:k], gd["h_expo_F"][:k], 1e-9)
+    f, h, L, x0 = O.D_opt_design(80, 200, randseed=10)
+    x, F, Gamma, G, T = O.ABPG_expo(f, h, L, x0, gamma0=3, maxitrs=300, theta_eq=True)
+    k = _prefix(Gamma, gd["r_expo_Gamma"], 1e-12)
+    assert k >= 200
+    _check(F[:k], gd["r_expo_F"][:k], 1e-10)
+    x, F, Gamma, G, T = O.ABPG_expo(f, h, L, x0, gamma0=2.5, maxitrs=200, theta_eq=False, checkdiv=True,
+                                    Gmargin=5, restart=True)
+    k = _prefix(Gamma, gd["r_expo2_Gamma"], 1e-12)        # decision-stable prefix (see the note above)
+    assert k >= 40, k
+    _check(F[:40], gd["r_expo2_F"][:40], 1e-10)
+    _check(F[:k], gd["r_expo2_F"][:k], 1e-4)
+    x, F, G, T = O.ABDA(f, h, L, x0, gamma=2, maxitrs=300, theta_eq=True)
+    _check(F, gd["r_abda_F"], 1e-11); _check(x, gd["r_abda_x"], 1e-11)
+    x, F, Ls, T = O.FW_alg_div_step(f, h, L, x0, lmo=O.lmo_simplex(), maxitrs=300, gamma=2.0, ls_ratio=2)
+    _check(F, gd["r_fwdiv_F"], 1e-11); _check(Ls, gd["r_fwdiv_Ls"], 1e-12)
+
+
+def test_kyinit_matches_reference():
+    gd = golden("next_rows")
+    f, h, L, x0 = O.D_opt_design(30, 1000, randseed=4)
+    np.random.seed(99)
+    xky = O.D_opt_KYinit(f.H)
+    np.testing.assert_array_equal(xky, gd["ky_x"])
+    assert np.count_nonzero(xky) <= 60 and abs(xky.sum() - 1) < 1e-14
+    # n <= 2m falls back to the uniform point (applications.py:67-68)
+    np.testing.assert_array_equal(O.D_opt_KYinit(np.zeros((30, 60))), np.ones(60) / 60)

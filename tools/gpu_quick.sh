@@ -1,9 +1,9 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -q --timeout 600 -x > gpurun_out/tests.log 2>&1
+timeout -k 10 900 python -m pytest tests -m gpu -q --timeout 600 > gpurun_out/tests.log 2>&1
 rc=$?; tail -n 5 gpurun_out/tests.log
 if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
-for a in "--steps 10 --warmup 3 --no-cpu-baseline" "--m 512 --n 8192 --workload abpg --steps 100 --warmup 10 --no-cpu-baseline" "--m 512 --n 8192 --workload abpg --steps 100 --warmup 10 --no-cpu-baseline --instances-per-gpu 4" "--m 512 --n 8192 --workload abpg --steps 100 --warmup 10 --no-cpu-baseline --instances-per-gpu 8" "--m 512 --n 8192 --workload abpg_gain --steps 100 --warmup 10 --no-cpu-baseline --instances-per-gpu 8"; do
+for a in "--steps 10 --warmup 3 --no-cpu-baseline"; do
 timeout -k 10 300 python bench.py $a 2>&1 | tail -n 1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
