@@ -34,6 +34,8 @@ _SIGS = {
     "accbpg_dopt_gram": (C.c_int, [_P, _P, _P]),
     "accbpg_dopt_factor": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),
     "accbpg_dopt_grad": (C.c_int, [_P, _P]),
+    "accbpg_dopt_gram_lincomb": (C.c_int, [_P, C.c_double, _P, C.c_double, _P, _P]),
+    "accbpg_dopt_eval_gram": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_double), _P]),
     "accbpg_vec_workspace_doubles": (C.c_int64, [C.c_int64]),
     "accbpg_burg_simplex_div_prox": (C.c_int, [_P, _P, C.c_double, C.c_double, C.c_int64, _P, _P,
                                                C.POINTER(C.c_int), _P]),
@@ -55,6 +57,7 @@ _SIGS = {
     "accbpg_dopt_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "accbpg_dopt_profile_reset": (C.c_int, [_P]),
     "accbpg_mfma_f64_peak": (C.c_int, [C.c_int, C.POINTER(C.c_double), _P]),
+    "accbpg_debug_chol_variant": (C.c_int, [_P, C.c_int]),
     "accbpg_debug_gram_variant": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "accbpg_test_gemm": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64,
                                    C.c_int64, C.c_int, C.c_double, C.c_double, C.c_int, _P]),

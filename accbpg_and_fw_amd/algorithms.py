@@ -25,6 +25,15 @@ def _divergences(h, g, x, y, z, z_prev):
     return vec_dot_diff(g, x, y), h.divergence(x, y), h.divergence(z, z_prev)
 
 
+def _lin(f):
+    """True when f is this package's D-optimal objective with Gram-matrix reuse switched on."""
+    return bool(getattr(f, "_lin", False))
+
+
+def _value(f, x, combo=None):
+    return f.func_grad_combo(x, combo, 0) if _lin(f) else f(x)
+
+
 def _drain(gen):
     """Run a step generator to completion and return its result."""
     while True:
@@ -128,9 +137,10 @@ def ABPG_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=False,
     z = x.clone()
     theta = 1.0
     kk = 0
+    xcombo = None
     k = -1
     for k in range(maxitrs):
-        F[k] = f(x) + h.extra_Psi(x)                            # :135-136
+        F[k] = _value(f, x, xcombo) + h.extra_Psi(x)            # :135-136
         T[k] = time.time() - t_start
 
         z_prev, x_prev = z, x
@@ -140,9 +150,15 @@ def ABPG_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=False,
             theta = gamma / (kk + gamma)
 
         y = vec_axpby(1 - theta, x, theta, z_prev)              # :147
-        g = f.gradient(y)                                       # :148
+        if _lin(f):
+            g = f.func_grad_combo(y, (1 - theta, x_prev, theta, z_prev), 1)
+        else:
+            g = f.gradient(y)                                   # :148
         z = h.div_prox_map(z_prev, g, theta ** (gamma - 1) * L)  # :149
         x = vec_axpby(1 - theta, x, theta, z)                   # :150
+        if _lin(f):
+            f.ensure_gram(z)                                    # the one O(m^2 n) product of this iteration
+            xcombo = (1 - theta, x_prev, theta, z)
 
         _, dxy, dzz = _divergences(h, None, x, y, z, z_prev)    # :153-154
         Gdr = dxy / dzz / theta ** gamma                        # :155
@@ -205,9 +221,10 @@ def ABPG_gain_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, G0=1,
     theta = 1.0
     kk = 0
     Gdr = 0.0
+    xcombo = None
     k = -1
     for k in range(maxitrs):
-        F[k] = f(x) + h.extra_Psi(x)                            # :347-348
+        F[k] = _value(f, x, xcombo) + h.extra_Psi(x)            # :347-348
         T[k] = time.time() - t_start
 
         z_prev, x_prev = z, x
@@ -224,9 +241,15 @@ def ABPG_gain_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, G0=1,
                     theta = theta_prev * ((1 + alpha * (gamma - 1)) / (gamma * alpha + theta_prev))
 
             y = vec_axpby(1 - theta, x_prev, theta, z_prev)     # :369
-            fy, g = f.func_grad(y)                              # :371
+            if _lin(f):
+                fy, g = f.func_grad_combo(y, (1 - theta, x_prev, theta, z_prev), 2)
+            else:
+                fy, g = f.func_grad(y)                          # :371
             z = h.div_prox_map(z_prev, g, theta ** (gamma - 1) * G * L)   # :373
             x = vec_axpby(1 - theta, x_prev, theta, z)          # :374
+            if _lin(f):
+                f.ensure_gram(z)                                # the one O(m^2 n) product of this pass
+                xcombo = (1 - theta, x_prev, theta, z)
 
             lin, dxy, dzz = _divergences(h, g, x, y, z, z_prev)  # :377-378 and the dot of :387
             if dzz < epsilon:                                   # :379-380
@@ -237,7 +260,7 @@ def ABPG_gain_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, G0=1,
             if checkdiv:
                 searching = (Gdr > G)                           # :385
             else:
-                searching = (f(x) > fy + lin + theta ** gamma * G * L * dzz)   # :387
+                searching = (_value(f, x, xcombo) > fy + lin + theta ** gamma * G * L * dzz)   # :387
 
             if searching:
                 G = G * ls_inc                                  # :390

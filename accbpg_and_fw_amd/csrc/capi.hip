@@ -146,6 +146,58 @@ extern "C" int accbpg_dopt_func_grad(accbpg_dopt* h, const double* x_dev, int fl
     return ACCBPG_OK;
 }
 
+namespace accbpg {
+__global__ void lincomb_kernel(double a, const double* __restrict__ G1, double b, const double* __restrict__ G2,
+                               int64_t total, double* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 2;
+    for (int64_t e = 2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x); e < total; e += stride) {
+        if (e + 1 < total) {
+            const double2 u = *reinterpret_cast<const double2*>(G1 + e);
+            const double2 v = *reinterpret_cast<const double2*>(G2 + e);
+            double2 r;
+            r.x = a * u.x + b * v.x;
+            r.y = a * u.y + b * v.y;
+            *reinterpret_cast<double2*>(out + e) = r;
+        } else {
+            out[e] = a * G1[e] + b * G2[e];
+        }
+    }
+}
+}  // namespace accbpg
+
+/* out <- a*G1 + b*G2 over m*m doubles: the Gram matrix is linear in x, so the Gram matrix at
+ * a*x1 + b*x2 is this combination of the Gram matrices at x1 and x2 (out may alias G1 or G2). */
+extern "C" int accbpg_dopt_gram_lincomb(accbpg_dopt* h, double a, const double* G1_dev, double b,
+                                        const double* G2_dev, double* out_dev) {
+    if (!h || !G1_dev || !G2_dev || !out_dev) return ACCBPG_ERR_ARG;
+    const int64_t total = h->m * h->m;
+    lincomb_kernel<<<2048, 256, 0, h->stream>>>(a, G1_dev, b, G2_dev, total, out_dev);
+    ACC_HIP(hipGetLastError());
+    return ACCBPG_OK;
+}
+
+/* func_grad from a Gram matrix already formed (by accbpg_dopt_gram or accbpg_dopt_gram_lincomb):
+ * Cholesky + log det, and for flag 1/2 the gradient (functions.py:48-58 without :46). */
+extern "C" int accbpg_dopt_eval_gram(accbpg_dopt* h, const double* gram_dev, int flag, double* f_host, double* g_dev) {
+    if (!h || !gram_dev || flag < 0 || flag > 2) return ACCBPG_ERR_ARG;
+    if (flag != 0 && !g_dev) return ACCBPG_ERR_ARG;
+    if (gram_dev != h->Lbuf)
+        ACC_HIP(hipMemcpyAsync(h->Lbuf, gram_dev, sizeof(double) * h->m * h->m, hipMemcpyDeviceToDevice, h->stream));
+    ACC_TRY(launch_cholesky(h, h->Lbuf));
+    if (flag != 0) {
+        ACC_TRY(launch_trtri(h));
+        ACC_TRY(launch_colnorm(h, h->Wbuf, g_dev, -1.0));
+    }
+    ACC_TRY(read_status(h));
+    const int* fl = reinterpret_cast<const int*>(h->hpin + 16);
+    if (fl[FLAG_NOT_PD]) {
+        set_last_error("HXHT is singular or not positive definite");
+        return ACCBPG_ERR_NOT_PD;
+    }
+    if (f_host) *f_host = -h->hpin[0];
+    return ACCBPG_OK;
+}
+
 extern "C" int accbpg_dopt_profile_enable(accbpg_dopt* h, int enable) {
     if (!h) return ACCBPG_ERR_ARG;
     h->prof_on = enable != 0;
@@ -186,6 +238,12 @@ extern "C" int accbpg_test_gemm(const double* A_dev, int64_t lda, const double* 
     if (!A_dev || !B_dev || !C_dev || M <= 0 || N <= 0 || K <= 0) return ACCBPG_ERR_ARG;
     return launch_test_gemm(A_dev, lda, B_dev, ldb, C_dev, ldc, M, N, K, b_kmajor, alpha, beta, config,
                             (hipStream_t)stream);
+}
+
+extern "C" int accbpg_debug_chol_variant(accbpg_dopt* h, int bits) {
+    if (!h) return ACCBPG_ERR_ARG;
+    h->chol_dbg = bits;
+    return ACCBPG_OK;
 }
 
 extern "C" int accbpg_debug_gram_variant(accbpg_dopt* h, const double* x_dev, int variant, int iters, double* ms_host) {

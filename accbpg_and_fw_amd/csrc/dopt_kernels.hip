@@ -393,17 +393,14 @@ struct Blk64 {
     }
 };
 
-// 1/sqrt(d) and sqrt(d) to fp64 accuracy from v_rsq_f64 plus Newton/Heron corrections (the pivot
-// chain of the factorisation is latency-bound; this is half the dependent depth of sqrt + divide).
-__device__ __forceinline__ void rsqrt_sqrt(double d, double& rp, double& piv) {
+// 1/sqrt(d) to fp64 accuracy: v_rsq_f64 plus two Newton steps (the pivot chain of the factorisation
+// is latency-bound; this is a third of the dependent depth of sqrt followed by a divide).
+__device__ __forceinline__ double rsqrt_newton(double d) {
     double y = __builtin_amdgcn_rsq(d);
-    double h = 0.5 * d;
-    y = y * fma(-h * y, y, 1.5);
-    y = y * fma(-h * y, y, 1.5);
-    double sq = d * y;
-    sq = fma(fma(-sq, sq, d), 0.5 * y, sq);
-    rp = y;
-    piv = sq;
+    const double h = -0.5 * d;
+    y = y * fma(h * y, y, 1.5);
+    y = y * fma(h * y, y, 1.5);
+    return y;
 }
 
 // quad broadcast on DPP: every lane of a quad gets lane `src`'s value, no LDS round trip
@@ -426,8 +423,8 @@ __device__ __forceinline__ double quad_bcast(double v) {
 //   a[r][cc] -= (l_rc / piv) * a[cc][c].
 // Finished columns and entries above the diagonal carry garbage that is never read back.
 __device__ __forceinline__ void potrf64_lds(const double* __restrict__ S, double* __restrict__ Lo,
-                                            double* __restrict__ colbuf /* 2 x 64 (+64 pad) */,
-                                            double* __restrict__ pvbuf /* 2 x 2 */, int* __restrict__ badflag,
+                                            double* __restrict__ colbuf /* 2 x 64 (+64 junk) */,
+                                            double* __restrict__ pvbuf /* 2 */, int* __restrict__ badflag,
                                             int bs) {
     const int tid = threadIdx.x;
     const int r = tid & 63;
@@ -441,13 +438,18 @@ __device__ __forceinline__ void potrf64_lds(const double* __restrict__ S, double
         if (r == 0) {
             double d = a[0];
             if (!(d > 0.0)) { *badflag = 1; d = 1.0; }
-            double rp, piv;
-            rsqrt_sqrt(d, rp, piv);
-            pvbuf[0] = rp;
-            pvbuf[1] = piv;
+            pvbuf[0] = rsqrt_newton(d);
         }
     }
     __syncthreads();
+    // The step body is branch-free (one basic block between barriers) so that the compiler can
+    // overlap the pivot chain -- LDS reads, two multiplies, one FMA, 1/sqrt by v_rsq_f64 + Newton,
+    // one 8-byte publish -- with the sixteen register updates: every lane computes the reciprocal
+    // square root of ITS candidate for the next pivot, and stores that are not the owner's go to a
+    // junk slot instead of being skipped.  The diagonal of L (a true square root) is off that chain:
+    // each row keeps its pivot value and takes the root after the loop.
+    double* junk = colbuf + 2 * NB;                               // NB doubles nobody relies on
+    double dsave = 1.0;
 #pragma unroll 1
     for (int cg = 0; cg < NB / 4; ++cg) {
 #pragma unroll
@@ -455,46 +457,47 @@ __device__ __forceinline__ void potrf64_lds(const double* __restrict__ S, double
             const int c = 4 * cg + ci;
             const int par = ci & 1;                               // c & 1
             const double* col = colbuf + par * NB;
-            const double rp = pvbuf[2 * par], piv = pvbuf[2 * par + 1];
-            const double lrc = (r == c) ? piv : col[r] * rp;
-            if (q == ci) Lo[r * SP + c] = (r >= c) ? lrc : 0.0;
-            const double w = lrc * rp;
-            // column c+1 first: it heads the dependent chain of the next step.  It lives in a[0] of
-            // wave ci+1, or (ci == 3) in a[1] of wave 0.
-            const int qn = (ci + 1) & 3;
-            const int tn = (ci == 3) ? 1 : 0;
-            if (q == qn && c + 1 < NB) {
-                const double an = fma(-w, col[c + 1], a[tn]);
-                a[tn] = an;
-                colbuf[(par ^ 1) * NB + r] = an;
-                if (r == c + 1) {
-                    double d = an;
-                    if (!(d > 0.0)) { if (c + 1 < bs) *badflag = 1; d = 1.0; }
-                    double rpn, pivn;
-                    rsqrt_sqrt(d, rpn, pivn);
-                    pvbuf[2 * (par ^ 1)] = rpn;
-                    pvbuf[2 * (par ^ 1) + 1] = pivn;
-                }
-            }
-            // the other live registers (reads past column 63 hit the pad; those registers are dead)
+            const double rp = pvbuf[par];
+            const double arc = col[r];
             const double* colq = col + 4 * cg + q;
             double cv[NB / 4];
 #pragma unroll
             for (int t = 0; t < NB / 4; ++t) cv[t] = colq[4 * t];   // one batch of independent reads (pad past 63)
-#pragma unroll
-            for (int t = 0; t < NB / 4; ++t) {
-                if (t == tn) {
-                    if (q != qn) a[t] = fma(-w, cv[t], a[t]);
-                } else {
-                    a[t] = fma(-w, cv[t], a[t]);
-                }
+            const double lrc = arc * rp;                          // row c itself: d * 1/sqrt(d) ~ sqrt(d), fixed below
+            dsave = (r == c) ? arc : dsave;
+            const double w = lrc * rp;
+            // column c+1 lives in a[0] of wave ci+1, or (ci == 3) in a[1] of wave 0
+            const int qn = (ci + 1) & 3;
+            const int tn = (ci == 3) ? 1 : 0;
+            a[tn] = fma(-w, cv[tn], a[tn]);                       // heads the dependent chain
+            const bool own_next = (q == qn);
+            {
+                double* dst = own_next ? (colbuf + (par ^ 1) * NB + r) : (junk + r);
+                *dst = a[tn];
+                const bool is_piv = own_next && (r == c + 1);
+                const bool nonpos = !(a[tn] > 0.0);
+                const double rpn = rsqrt_newton(fmax(a[tn], 1e-300));
+                double* pdst = is_piv ? (pvbuf + (par ^ 1)) : (junk + (r & 31));
+                *pdst = rpn;
+                int* bdst = (is_piv && nonpos && c + 1 < bs) ? badflag : reinterpret_cast<int*>(junk + NB - 2);
+                *bdst = 1;
             }
+            {
+                double* ldst = (q == ci) ? (Lo + r * SP + c) : (junk + 32 + (r & 15));
+                *ldst = (r >= c) ? lrc : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < NB / 4; ++t)
+                if (t != tn) a[t] = fma(-w, cv[t], a[t]);
             __syncthreads();
         }
 #pragma unroll
         for (int t = 0; t + 1 < NB / 4; ++t) a[t] = a[t + 1];
         a[NB / 4 - 1] = 0.0;
     }
+    // diagonal: L[r][r] = sqrt(pivot value of row r) (rows >= bs hold the identity padding: 1)
+    if (q == 0) Lo[r * SP + r] = sqrt(dsave);
+    __syncthreads();
 }
 
 // Solve X * L^T = P for the 64 rows of Xs in place, L = Lo (64x64 lower, unit-padded), right-looking:
@@ -541,9 +544,11 @@ __device__ __forceinline__ void trsm64_lds(double* __restrict__ Xs, const double
     }
 }
 
+// dbg (timing ablations only, wrong results unless 0): bit 0 skips the factorisation of the diagonal
+// block, bit 1 the panel solve, bit 2 the MFMA products.
 __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restrict__ A, int64_t lda, int64_t m,
                                                                int kprev, int T, double* __restrict__ logdet,
-                                                               int* __restrict__ flags) {
+                                                               int* __restrict__ flags, int dbg) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* Ak = lds;                       // 64 x SQ : L(i,kprev) operand image
     double* Bk = Ak + NB * SQ;              // 64 x SQ : L(kc,kprev) (or L(j,kprev)) operand image
@@ -621,11 +626,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restri
         bkk.to_lds(Bk, SQ);
         if (!diag) bik.to_lds(Ak, SQ);
         __syncthreads();
-        mma64(acc, Bk, Bk);                              // L(kc,kprev) L(kc,kprev)^T
-        if (!diag) mma64(pacc, Ak, Bk);                  // L(i,kprev) L(kc,kprev)^T
-        sub_acc64(S, acc, bs, bs, true);
+        if (!(dbg & 4)) {
+            mma64(acc, Bk, Bk);                          // L(kc,kprev) L(kc,kprev)^T
+            if (!diag) mma64(pacc, Ak, Bk);              // L(i,kprev) L(kc,kprev)^T
+            sub_acc64(S, acc, bs, bs, true);
+        }
     }
-    potrf64_lds(S, Lo, colbuf, pvbuf, badflag, bs);      // starts and ends with a barrier
+    if (!(dbg & 1)) potrf64_lds(S, Lo, colbuf, pvbuf, badflag, bs);      // starts and ends with a barrier
+    else { __syncthreads(); for (int e = tid; e < NB * SP; e += NTHREADS) Lo[e] = S[e]; __syncthreads(); }
     const bool bad = (*badflag != 0);
     if (diag) {
         Blk64 bl;
@@ -646,9 +654,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restri
     bp.to_lds(Xs, SP);
     if (tid < NB) rinv[tid] = (tid < bs) ? 1.0 / Lo[tid * SP + tid] : 0.0;
     __syncthreads();
-    if (kprev >= 0) sub_acc64(Xs, pacc, mi, bs, false);
+    if (kprev >= 0 && !(dbg & 4)) sub_acc64(Xs, pacc, mi, bs, false);
     __syncthreads();
-    trsm64_lds(Xs, Lo, rinv);
+    if (!(dbg & 2)) trsm64_lds(Xs, Lo, rinv);
     __syncthreads();
     bp.from_lds(Xs, SP);
     bp.store(Pik, lda, mi, bs, false);
@@ -920,7 +928,7 @@ int launch_cholesky(accbpg_dopt* h, double* A) {
         const int R = T - (kc + 1);
         const int nupd = (kprev >= 0) ? R * (R + 1) / 2 : 0;
         chol_step_kernel<<<npanel + nupd, NTHREADS, CHOL_LDS_BYTES, h->stream>>>(A, m, m, kprev, T, h->dscal,
-                                                                                 h->dflag);
+                                                                                 h->dflag, h->chol_dbg);
     }
     prof_end(h, PROF_CHOL);
     ACC_HIP(hipGetLastError());

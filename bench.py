@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--instances-per-gpu", type=int, default=1,
                     help="independent instances per GPU driven concurrently from host threads on separate "
                          "streams (BASELINE config 4: 64 x D_opt_design(512,8192) over 8 GPUs = 8 per GPU)")
+    ap.add_argument("--linear-gram", action="store_true",
+                    help="measure with Gram-matrix reuse through linearity switched on (extension); the "
+                         "default run reports it separately as linear_gram_variant")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     return ap.parse_args()
@@ -113,6 +116,8 @@ def main():
         V = make_instance(m, n, 1 + rank, device)
         f = acc.DOptimalObj(V)
         prof_obj = f
+    if args.linear_gram and not shard:
+        f.linear_gram(True)
     h = acc.BurgEntropySimplex()
     x0 = torch.full((n,), 1.0 / n, dtype=torch.float64, device=device)
     total = args.warmup + args.steps
@@ -173,6 +178,32 @@ def main():
     prof_obj.profile(False)
     calls = {k: f.calls[k] - calls0[k] for k in calls0}
 
+    # same workload once more with Gram-matrix reuse through linearity (extension, reported apart)
+    lin_variant = None
+    if (not args.linear_gram) and (not shard) and ipg == 1 and args.workload in ("abpg_gain", "abpg"):
+        f.linear_gram(True)
+        if args.workload == "abpg_gain":
+            gen2 = alg.ABPG_gain_steps(f, h, 1.0, x0, 2, total + 1, verbose=False)
+        else:
+            gen2 = alg.ABPG_steps(f, h, 1.0, x0, 2, total + 1, verbose=False)
+        for _ in range(args.warmup):
+            next(gen2)
+        gl0, vh0 = f.gram_launches, f.value_hits
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            next(gen2)
+        barrier()
+        dt = time.perf_counter() - t1
+        lin_variant = {"value": world * args.steps / dt, "unit": "iterations/s", "ms_per_step": 1e3 * dt / args.steps,
+                       "gram_launches_per_step": (f.gram_launches - gl0) / args.steps,
+                       "repeated_value_lookups_per_step": (f.value_hits - vh0) / args.steps,
+                       "note": "V diag(x) V^T is linear in x: Gram matrices at x, z stay resident and the ones at "
+                               "y and x+ are O(m^2) combinations; f at a vector object already evaluated (the "
+                               "line-search point, re-read as F[k+1]) is looked up; results equal to rounding "
+                               "(test_linear_gram_*)"}
+        f.linear_gram(False)
+
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -198,6 +229,9 @@ def main():
         kern = {k: {"ms_total": v[0], "launches": v[1], "ms_avg": (v[0] / v[1] if v[1] else None)}
                 for k, v in prof.items()}
         out["kernels"] = kern
+        if lin_variant is not None:
+            out["linear_gram_variant"] = lin_variant
+        out["config"]["linear_gram"] = bool(args.linear_gram)
         if args.workload in ("abpg_gain", "abpg", "bpg") and gram_cnt:
             # dominant kernel: Gram stream-K.  Algorithmic flops per launch = m^2 * n (SURVEY 8(d):
             # the SYRK share of 2 m^2 n + m^3/3 + 2 m n).

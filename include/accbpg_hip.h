@@ -70,6 +70,13 @@ int accbpg_dopt_gram(accbpg_dopt* h, const double* x_dev, double* gram_dev);
 int accbpg_dopt_factor(accbpg_dopt* h, const double* gram_dev, double* f_host);
 int accbpg_dopt_grad(accbpg_dopt* h, double* g_dev);
 
+/* Linearity of the Gram matrix in x (an extension with no reference counterpart; opt-in from the
+ * Python side): out <- a*G1 + b*G2 is the Gram matrix at a*x1 + b*x2 when G1, G2 are those at x1, x2;
+ * accbpg_dopt_eval_gram finishes func_grad from a Gram matrix (Cholesky, log det, gradient). */
+int accbpg_dopt_gram_lincomb(accbpg_dopt* h, double a, const double* G1_dev, double b,
+                             const double* G2_dev, double* out_dev);
+int accbpg_dopt_eval_gram(accbpg_dopt* h, const double* gram_dev, int flag, double* f_host, double* g_dev);
+
 /* ---- Burg entropy on the simplex: replaces BurgEntropy / BurgEntropySimplex ------------
  * (accbpg/functions.py:238-271, 326-356).  `ws_dev` is caller-provided scratch of at least
  * accbpg_vec_workspace_doubles(n) doubles. */
@@ -187,6 +194,9 @@ int accbpg_test_gemm(const double* A_dev, int64_t lda, const double* B_dev, int6
  * others drop global loads / LDS staging / the barrier / fragment reads and produce wrong data
  * into scratch).  Average milliseconds per launch over `iters` launches. */
 int accbpg_debug_gram_variant(accbpg_dopt* h, const double* x_dev, int variant, int iters, double* ms_host);
+/* Timing ablation bits for the Cholesky step kernel (development aid; 0 = product behaviour):
+ * 1 skip the diagonal-block factorisation, 2 skip the panel solve, 4 skip the MFMA products. */
+int accbpg_debug_chol_variant(accbpg_dopt* h, int bits);
 
 #ifdef __cplusplus
 }

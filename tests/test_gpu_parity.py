@@ -537,3 +537,36 @@ def test_kyinit_gpu(acc):
     assert abs(len(F) - len(gd["ky_away_F"])) <= 2
     _close(F[:k], gd["ky_away_F"][:k], 1e-8)
     assert np.max(np.abs(xs - gd["ky_away_x"])) < 1e-8
+
+
+# ------------------------------------------------------------------ Gram-matrix reuse through linearity
+@pytest.mark.parametrize("solver", ["abpg", "abpg_gain", "abpg_restart"])
+def test_linear_gram_reuse_matches_direct(acc, solver):
+    """Opt-in extension: V diag(x) V^T is linear in x, so the accelerated solvers can combine resident
+    Gram matrices instead of re-forming them.  Same trajectory as direct evaluation to rounding, with
+    one O(m^2 n) product per pass instead of two or three."""
+    gd = golden("traces_80x200")
+    f, h, L, x0 = acc.D_opt_design(80, 200, randseed=10)
+    if solver == "abpg":
+        run = lambda ff: acc.ABPG(ff, h, L, x0, gamma=2.0, maxitrs=400, theta_eq=True, verbose=False)
+        ref_x, ref_F = None, gd["abpg_F"][:400]
+    elif solver == "abpg_restart":
+        run = lambda ff: acc.ABPG(ff, h, L, x0, gamma=2.0, maxitrs=400, theta_eq=True, restart=True, verbose=False)
+        ref_x, ref_F = None, gd["abpgrs_F"][:400]
+    else:
+        run = lambda ff: acc.ABPG_gain(ff, h, L, x0, gamma=2, maxitrs=400, G0=0.1, theta_eq=True, verbose=False)
+        ref_x, ref_F = None, gd["gain_F"][:400]
+    base = run(f)
+    f2 = acc.DOptimalObj(f.H).linear_gram(True, refresh=25)
+    lin = run(f2)
+    assert np.max(np.abs(lin[0] - base[0])) < 1e-11
+    np.testing.assert_allclose(lin[1], base[1], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(lin[1], ref_F, rtol=1e-9, atol=1e-9)          # and the reference's trace
+    evals = f2.calls["value"] + f2.calls["grad"]
+    assert f2.gram_launches + f2.gram_combos <= evals + 450
+    assert f2.gram_launches < 0.62 * evals, (f2.gram_launches, f2.gram_combos, evals)
+    # plain evaluations still work on an object with reuse enabled
+    fx, g = f2.func_grad(x0, 2)
+    fb, gb = f.func_grad(x0, 2)
+    assert fx == fb
+    np.testing.assert_array_equal(g, gb)

@@ -1,0 +1,23 @@
+"""Time the Cholesky with parts of chol_step_kernel switched off (development aid)."""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import accbpg_and_fw_amd as acc
+from accbpg_and_fw_amd import _lib
+m, n = 2048, 32768
+V = torch.randn(m, n, dtype=torch.float64, device="cuda")
+f = acc.DOptimalObj(V)
+x = torch.full((n,), 1.0 / n, dtype=torch.float64, device="cuda")
+lib = _lib.load()
+names = {0: "full", 1: "no potrf", 2: "no trsm", 3: "no potrf, no trsm", 4: "no mfma", 7: "loads/stores only"}
+for bits in [0, 1, 2, 3, 4, 7, 0]:
+    lib.accbpg_debug_chol_variant(f._h, bits)
+    f.profile(True)
+    for _ in range(5):
+        try:
+            f(x)
+        except Exception:
+            pass
+    p = f.profile_read()
+    print("bits %d (%-18s) cholesky %.3f ms" % (bits, names[bits], p["cholesky"][0] / p["cholesky"][1]), flush=True)
+lib.accbpg_debug_chol_variant(f._h, 0)
