@@ -107,6 +107,76 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_kernel(
 
 // grid = ntiles * T::MI: workgroup (tile, part) sums fragment row `part` of the tile's slabs, so
 // the reduction reads the slabs with MI times the workgroups (HBM-bound pass, not 72 CUs' worth)
+// Direct-to-LDS version of the Gram kernel for interior tiles (same stream-K decomposition and
+// slabs): global_load_lds_dwordx4 into three rotating swizzled stages, loads two k-steps ahead,
+// counted vmcnt + raw barrier, x applied to the A fragments after the LDS read.
+// GV (timing ablations only): bit 0 = no loads inside the k-loop, bit 1 = no wait + barrier.
+template <class T, int GV = 0>
+__global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_glds_kernel(
+    const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n, const double* __restrict__ x,
+    const TileRC* __restrict__ tiles, int ntiles, int64_t kiters, int64_t per, double* __restrict__ slabs,
+    double* __restrict__ G, int64_t ldg) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int NLD = T::G_NA + T::G_NB + 1;                  // loads per wave per stage
+    const int64_t total = (int64_t)ntiles * kiters;
+    const int64_t it0 = min((int64_t)blockIdx.x * per, total);
+    const int64_t it1 = min(it0 + per, total);
+    T t;
+    int64_t it = it0;
+    int seg = 0;
+    while (it < it1) {
+        const int tile = (int)(it / kiters);
+        const int64_t kb = it - (int64_t)tile * kiters;
+        const int64_t ke = min(kiters, kb + (it1 - it));
+        const int64_t klast = ke - 1;
+        const int64_t row0 = (int64_t)tiles[tile].rb * T::BM;
+        const int64_t col0 = (int64_t)tiles[tile].cb * T::BN;
+        t.zero();
+        t.glds_setup_A(V, ldv, row0);
+        t.glds_setup_B_kc(V, ldv, col0);
+        auto issue = [&](int64_t ks, int buf) {
+            double* st = lds + buf * T::G_STAGE;
+            t.glds_issue(ks * BK, ks * BK, st);
+            t.glds_x(x, ks * BK, st);
+        };
+        __builtin_amdgcn_s_barrier();                           // previous segment's readers are done
+        issue(kb, 0);
+        issue(min(kb + 1, klast), 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");   // stage 0 landed (this wave's share)
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+#pragma unroll 1
+        for (int64_t ks = kb; ks < ke; ++ks) {
+            int nx2 = cur + 2;
+            if (nx2 >= 3) nx2 -= 3;
+            const double* st = lds + cur * T::G_STAGE;
+            t.template read_frag_g<0, true>(st, 0);
+            t.template read_frag_g<1, true>(st, 1);
+            t.template mma_frag<0>();
+            if constexpr (!(GV & 1)) issue(min(ks + 2, klast), nx2);   // that buffer was last read in step ks-1
+            t.template read_frag_g<0, true>(st, 2);
+            t.template mma_frag<1>();
+            t.template read_frag_g<1, true>(st, 3);
+            t.template mma_frag<0>();
+            t.template mma_frag<1>();
+            // stage ks+1 (issued one step ago) must have landed: all but the newest NLD loads done
+            if constexpr (!(GV & 2)) {
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLD) : "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            cur = (cur + 1 == 3) ? 0 : cur + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // redundant tail loads retire before LDS is reused
+        if (kb == 0 && ke == kiters) {
+            t.store_C(G, ldg, row0, col0, m, m, 1.0, 0.0, true);
+        } else {
+            t.store_slab(slabs + ((int64_t)blockIdx.x * 2 + (seg == 0 ? 0 : 1)) * T::SLAB_DOUBLES);
+        }
+        it += ke - kb;
+        ++seg;
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(NTHREADS, 2) void gram_fixup_kernel(
     const TileRC* __restrict__ tiles, int ntiles, int64_t kiters, int64_t per, const double* __restrict__ slabs,
@@ -220,6 +290,95 @@ __global__ __launch_bounds__(NTHREADS, 1) void colnorm_kernel(
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < T::WAVES_M; ++w) s += red[w][c];
+        if (col0 + c < n) out[col0 + c] = sign * s;
+    }
+}
+
+// Direct-to-LDS version of the gradient kernel for interior sizes.
+template <class T>
+__global__ __launch_bounds__(NTHREADS, 1) void colnorm_glds_kernel(
+    const double* __restrict__ W, int64_t ldw, const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n,
+    double* __restrict__ out, double sign) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* red = lds + 3 * T::G_STAGE;                         // [4][BN] behind the stages
+    constexpr int NLD = T::G_NA + T::G_NB;
+    const int64_t col0 = (int64_t)blockIdx.x * T::BN;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / T::WAVES_N, wn = wave % T::WAVES_N;
+    const int lr = lane & 15;
+    double colsum[T::NI];
+#pragma unroll
+    for (int j = 0; j < T::NI; ++j) colsum[j] = 0.0;
+    T t;
+    const int nrb = (int)(m / T::BM);
+    for (int rb = 0; rb < nrb; ++rb) {
+        const int64_t row0 = (int64_t)rb * T::BM;
+        const int64_t ksteps = (row0 + T::BM) / BK;             // W is lower triangular
+        const int64_t klast = ksteps - 1;
+        t.zero();
+        t.glds_setup_A(W, ldw, row0);
+        t.glds_setup_B_km(V, ldv, col0);
+        auto issue = [&](int64_t ks, int buf) {
+            t.glds_issue(ks * BK, ks * BK * ldv, lds + buf * T::G_STAGE);
+        };
+        __builtin_amdgcn_s_barrier();
+        issue(0, 0);
+        issue(min((int64_t)1, klast), 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+#pragma unroll 1
+        for (int64_t ks = 0; ks < ksteps; ++ks) {
+            int nx2 = cur + 2;
+            if (nx2 >= 3) nx2 -= 3;
+            const double* st = lds + cur * T::G_STAGE;
+            const int64_t kd = ks * BK - row0;
+            int mi_lo = 0;
+            if (kd > 0) {
+                const int64_t num = kd - 15 - 16 * wm;
+                mi_lo = num > 0 ? (int)((num + 16 * T::WAVES_M - 1) / (16 * T::WAVES_M)) : 0;
+            }
+            t.template read_frag_g<0, false>(st, 0);
+            t.template read_frag_g<1, false>(st, 1);
+            t.template mma_frag<0>(mi_lo);
+            issue(min(ks + 2, klast), nx2);
+            t.template read_frag_g<0, false>(st, 2);
+            t.template mma_frag<1>(mi_lo);
+            t.template read_frag_g<1, false>(st, 3);
+            t.template mma_frag<0>(mi_lo);
+            t.template mma_frag<1>(mi_lo);
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLD) : "memory");
+            __builtin_amdgcn_s_barrier();
+            cur = (cur + 1 == 3) ? 0 : cur + 1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < T::NI; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < T::MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s += t.acc[i][j][r] * t.acc[i][j][r];
+            colsum[j] += s;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < T::NI; ++j) {
+        double s = colsum[j];
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        colsum[j] = s;
+    }
+    __syncthreads();
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < T::NI; ++j) red[wm * T::BN + wn * T::WN + 16 * j + lr] = colsum[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < T::BN; c += NTHREADS) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < T::WAVES_M; ++w) s += red[w * T::BN + c];
         if (col0 + c < n) out[col0 + c] = sign * s;
     }
 }
@@ -775,6 +934,45 @@ int build_plans(accbpg_dopt* h) {
     grid = (int)((total + per - 1) / per);
     h->gram_grid = grid;
     h->gram_per = (int)per;
+    // XCD-aware order.  Workgroups whose ranges start a whole number of tiles apart run the same
+    // k-step at the same time; with `per` steps per workgroup those are workgroups dw = kiters/g apart
+    // (g = gcd(per, kiters)), D = per/g tiles apart, and when dw is a multiple of 8 they share an XCD
+    // (round-robin placement: speed only, never correctness).  Arrange the list so that positions
+    // i, i+D, i+2D, ... hold a compact 2 x 4 block of tiles (2 A panels + 4 B panels feed 8 tiles),
+    // which those workgroups then stream through the same L2 together.
+    {
+        auto gcd64 = [](int64_t a, int64_t b) { while (b) { int64_t t = a % b; a = b; b = t; } return a; };
+        const int64_t g = gcd64(per, h->kiters);
+        const int64_t D = per / g, dw = h->kiters / g;
+        const int nt = (int)tl.size();
+        if (h->big && D > 1 && D < nt && nt % D == 0 && dw % 8 == 0) {
+            const int gs = (int)(nt / D);
+            // sequence in which consecutive runs are compact: row-block pairs, then 4 column blocks at a time
+            std::vector<TileRC> seq;
+            std::vector<char> used(tl.size(), 0);
+            auto find = [&](int rb, int cb) {
+                for (size_t i = 0; i < tl.size(); ++i)
+                    if (!used[i] && tl[i].rb == rb && tl[i].cb == cb) return (int)i;
+                return -1;
+            };
+            for (int rp = nrb - 2 + (nrb & 1); rp >= -1; rp -= 2)
+                for (int c4 = 0; c4 < ncb; c4 += 4)
+                    for (int dr = 0; dr < 2; ++dr)
+                        for (int dc = 0; dc < 4; ++dc) {
+                            const int rb = rp + dr, cb = c4 + dc;
+                            if (rb < 0 || rb >= nrb || cb >= ncb) continue;
+                            // only full 2x4 blocks first; ragged remainders are appended below
+                            const int i = find(rb, cb);
+                            if (i >= 0 && find(rp + (1 - dr), cb) != -2) { used[i] = 1; seq.push_back(tl[i]); }
+                        }
+            for (size_t i = 0; i < tl.size(); ++i)
+                if (!used[i]) seq.push_back(tl[i]);
+            std::vector<TileRC> perm(tl.size());
+            for (int i = 0; i < (int)D; ++i)
+                for (int j = 0; j < gs; ++j) perm[(size_t)D * j + i] = seq[(size_t)i * gs + j];
+            tl.swap(perm);
+        }
+    }
     ACC_HIP(hipMalloc(&h->tiles, sizeof(TileRC) * tl.size()));
     ACC_HIP(hipMemcpy(h->tiles, tl.data(), sizeof(TileRC) * tl.size(), hipMemcpyHostToDevice));
     ACC_HIP(hipMalloc(&h->slabs, sizeof(double) * (size_t)grid * 2 * BM * BN));
@@ -834,6 +1032,8 @@ int build_plans(accbpg_dopt* h) {
     ACC_TRY(set_lds(gemm_ops_kernel<TileSmall<true>>, TileSmall<true>::LDS_BYTES));
     ACC_TRY(set_lds(gemm_ops_kernel<TileSmall<false>>, TileSmall<false>::LDS_BYTES));
     ACC_TRY(set_lds(chol_step_kernel, CHOL_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>>, TileBig<false, false>::G_LDS_BYTES));
+    ACC_TRY(set_lds(colnorm_glds_kernel<TileBig<true, false>>, TileBig<true, false>::G_LDS_BYTES + 4 * 128 * 8));
     ACC_TRY(set_lds(gemm_big_kernel<TileBig<true>>, TileBig<true>::LDS_BYTES));
     ACC_TRY(set_lds(gemm_big_kernel<TileBig<false>>, TileBig<false>::LDS_BYTES));
     return ACCBPG_OK;
@@ -842,8 +1042,19 @@ int build_plans(accbpg_dopt* h) {
 template <class T>
 static void gram_launch_t(accbpg_dopt* h, const double* x, double* gram) {
     prof_begin(h, PROF_GRAM);
-    gram_streamk_kernel<T><<<h->gram_grid, NTHREADS, T::LDS_BYTES, h->stream>>>(
-        h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->slabs, gram, h->m, h->vec_ok);
+    if constexpr (!T::EDGE && T::BM == 256) {
+        if (h->use_glds)
+            gram_streamk_glds_kernel<T><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
+                h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->slabs, gram, h->m);
+        else
+            gram_streamk_kernel<T><<<h->gram_grid, NTHREADS, T::LDS_BYTES, h->stream>>>(
+                h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->slabs, gram, h->m,
+                h->vec_ok);
+    } else {
+        gram_streamk_kernel<T><<<h->gram_grid, NTHREADS, T::LDS_BYTES, h->stream>>>(
+            h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->slabs, gram, h->m,
+            h->vec_ok);
+    }
     prof_end(h, PROF_GRAM);
     prof_begin(h, PROF_GRAMFIX);
     gram_fixup_kernel<T><<<h->ntiles * T::MI, NTHREADS, 0, h->stream>>>(h->tiles, h->ntiles, h->kiters, h->gram_per,
@@ -862,7 +1073,14 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
 #define ACC_LAUNCH_VAR(VV)                                                                                       \
     gram_streamk_kernel<T, VV><<<h->gram_grid, NTHREADS, T::LDS_BYTES, h->stream>>>(                             \
         h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->slabs, h->Tbuf, h->m, h->vec_ok)
+#define ACC_LAUNCH_G(GG)                                                                                         \
+    gram_streamk_glds_kernel<T, GG><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(                      \
+        h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->slabs, h->Tbuf, h->m)
         switch (var) {
+            case 10: ACC_LAUNCH_G(0); break;
+            case 11: ACC_LAUNCH_G(1); break;
+            case 12: ACC_LAUNCH_G(2); break;
+            case 13: ACC_LAUNCH_G(3); break;
             case 0: ACC_LAUNCH_VAR(0); break;
             case 1: ACC_LAUNCH_VAR(1); break;
             case 2: ACC_LAUNCH_VAR(2); break;
@@ -871,6 +1089,9 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
         }
 #undef ACC_LAUNCH_VAR
     };
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 1>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 2>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 3>, T::G_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 1>, T::LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 2>, T::LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 3>, T::LDS_BYTES));
@@ -963,7 +1184,11 @@ int launch_colnorm(accbpg_dopt* h, const double* W, double* out, double sign) {
     const bool vw = ((reinterpret_cast<uintptr_t>(W) & 15) == 0) && ((h->m & 1) == 0);
     if (h->big) {
         const bool interior = vw && h->vec_ok && (h->m % 256 == 0) && (h->n % 128 == 0);
-        if (interior) colnorm_launch_t<TileBig<true, false>>(h, W, out, sign, vw);
+        if (interior && h->use_glds) {
+            using T = TileBig<true, false>;
+            colnorm_glds_kernel<T><<<(int)(h->n / T::BN), NTHREADS, T::G_LDS_BYTES + 4 * T::BN * 8, h->stream>>>(
+                W, h->m, h->V, h->ldv, h->m, h->n, out, sign);
+        } else if (interior) colnorm_launch_t<TileBig<true, false>>(h, W, out, sign, vw);
         else colnorm_launch_t<TileBig<true, true>>(h, W, out, sign, vw);
     } else {
         const bool interior = vw && h->vec_ok && (h->m % 64 == 0) && (h->n % 64 == 0);

@@ -216,6 +216,105 @@ struct Tile {
         mma_frag<1>(mi_lo);
     }
 
+    // ---- direct-to-LDS staging (interior tiles only) --------------------------------------
+    // global_load_lds_dwordx4 writes one wave-instruction's 64 x 16 bytes LINEARLY into LDS, so the
+    // images are unpadded and the bank-conflict fix is an XOR swizzle applied to the per-lane SOURCE
+    // address and, identically, to the fragment read address:
+    //   k-contiguous image [rows][16]: 16-byte chunk c of row r sits at chunk c ^ ((r >> 1) & 7)
+    //     (the 32-lane group of a ds_read_b64 -- 16 rows x 2 k -- then covers all 64 banks);
+    //   k-major image [16][BN]       : column col of row k sits at col ^ (16 * (k & 1)).
+    // Three stages of (A image, B image, 32 doubles of x) rotate; loads run two k-steps ahead and
+    // are retired with a counted s_waitcnt vmcnt, never drained inside the loop.
+    static constexpr int G_A = BM * BK;
+    static constexpr int G_B = BN * BK;
+    static constexpr int G_X = 32;
+    static constexpr int G_STAGE = G_A + G_B + G_X;
+    static constexpr int G_LDS_BYTES = 3 * G_STAGE * 8;
+    static constexpr int G_NA = BM / 32;                 // glds per wave, A image
+    static constexpr int G_NB = BKM ? BK / 4 : BN / 32;  // glds per wave, B image
+
+    static __device__ __forceinline__ void glds16(const double* __restrict__ src, double* __restrict__ dst) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+    // per-lane source pointers of the pieces this wave moves, for k-step 0 (set once per tile
+    // segment; a k-step only adds a scalar offset)
+    const double* gpa[G_NA];
+    const double* gpb[G_NB];
+    __device__ __forceinline__ void glds_setup_A(const double* __restrict__ A, int64_t lda, int64_t row0) {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+        for (int p = 0; p < G_NA; ++p) {
+            const int q = wave + 4 * p;                          // 1-KiB piece = rows 8q .. 8q+7
+            const int row = 8 * q + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            gpa[p] = A + (row0 + row) * lda + 2 * c;
+        }
+    }
+    __device__ __forceinline__ void glds_setup_B_kc(const double* __restrict__ B, int64_t ldb, int64_t col0) {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+        for (int p = 0; p < G_NB; ++p) {
+            const int q = wave + 4 * p;
+            const int row = 8 * q + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            gpb[p] = B + (col0 + row) * ldb + 2 * c;
+        }
+    }
+    __device__ __forceinline__ void glds_setup_B_km(const double* __restrict__ B, int64_t ldb, int64_t col0) {
+        static_assert(!BKM || BN == 128, "one 1-KiB piece per k-row");
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+        for (int p = 0; p < G_NB; ++p) {
+            const int kr = wave + 4 * p;                         // k-row of the tile
+            const int c = lane ^ (8 * (kr & 1));                 // source chunk (2 columns) for LDS chunk `lane`
+            gpb[p] = B + (int64_t)kr * ldb + col0 + 2 * c;
+        }
+    }
+    // issue the pieces of one k-step: ka / kb = element offsets of that step in A / B
+    __device__ __forceinline__ void glds_issue(int64_t ka, int64_t kb, double* __restrict__ stage) const {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+        for (int p = 0; p < G_NA; ++p) glds16(gpa[p] + ka, stage + (wave + 4 * p) * 128);
+#pragma unroll
+        for (int p = 0; p < G_NB; ++p) glds16(gpb[p] + kb, stage + G_A + (wave + 4 * p) * 128);
+    }
+    // 32 doubles of x (16 used) behind the images; every wave writes the same bytes so that all
+    // waves carry the same number of outstanding loads
+    __device__ __forceinline__ void glds_x(const double* __restrict__ x, int64_t k0, double* __restrict__ stage) const {
+        const int lane = threadIdx.x & 63;
+        const float* src = reinterpret_cast<const float*>(x + k0) + (lane & 31);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(stage + G_A + G_B), 4, 0, 0);
+    }
+    // fragment group kk of a swizzled stage -> register set SET; SCALE multiplies the A fragments by
+    // x[k] (the weighted Gram matrix: (V*x) of functions.py:46)
+    template <int SET, bool SCALE>
+    __device__ __forceinline__ void read_frag_g(const double* __restrict__ stage, int kk) {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+        const int lr = lane & 15, lq = lane >> 4;
+        const int sw = (lr >> 1) & 7;
+        const int koff = 2 * ((2 * kk + (lq >> 1)) ^ sw) + (lq & 1);      // swizzled position of k = 4kk+lq
+        const double* as = stage + (16 * wm + lr) * BK + koff;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[SET][i] = as[i * 16 * WAVES_M * BK];
+        if constexpr (BKM) {
+            const double* bs = stage + G_A + (4 * kk + lq) * BN + wn * WN + lr;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fb[SET][j] = bs[16 * (j ^ (lq & 1))];
+        } else {
+            const double* bs = stage + G_A + (wn * WN + lr) * BK + koff;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fb[SET][j] = bs[j * 16 * BK];
+        }
+        if constexpr (SCALE) {
+            const double xk = stage[G_A + G_B + 4 * kk + lq];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[SET][i] *= xk;
+        }
+    }
+
     // ---- epilogues -----------------------------------------------------------------------
     // C[row][col] = alpha*acc + beta*C, guarded; lower_only drops elements with col > row.
     __device__ __forceinline__ void store_C(double* __restrict__ C, int64_t ldc, int64_t row0, int64_t col0,
