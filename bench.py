@@ -237,13 +237,21 @@ def main():
             # the SYRK share of 2 m^2 n + m^3/3 + 2 m n).
             flops = float(m) * m * n
             achieved = flops / (gram_ms / gram_cnt * 1e-3) * 1e-12
-            out["roofline"] = {"bound": "mfma", "kernel": "gram_streamk_kernel", "achieved": achieved,
+            traffic = None
+            try:        # HBM bytes per launch from the committed PMC passes (same workload only)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+                if (m, n) == (2048, 32768):
+                    traffic = tj["gram_streamk_glds_kernel"]["hbm_bytes"]
+            except Exception:
+                traffic = None
+            out["roofline"] = {"bound": "mfma", "kernel": "gram_streamk_glds_kernel (weighted Gram matrix, stream-K)",
+                               "achieved": achieved,
                                "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                               "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                                "avg_launch_ms": gram_ms / gram_cnt, "launches": gram_cnt}
             if grad_cnt:
                 ga = flops / (grad_ms / grad_cnt * 1e-3) * 1e-12
-                out["roofline_grad_kernel"] = {"bound": "mfma", "kernel": "colnorm_kernel", "achieved": ga,
+                out["roofline_grad_kernel"] = {"bound": "mfma", "kernel": "colnorm_glds_kernel (triangular product + column norms)", "achieved": ga,
                                                "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                                                "frac": ga / PEAK_FP64_MFMA_TFLOPS,
                                                "avg_launch_ms": grad_ms / grad_cnt, "launches": grad_cnt}

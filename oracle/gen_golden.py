@@ -166,6 +166,19 @@ def large(accbpg, m=2048, n=32768, seed=10, iters=12):
          away_x=xa, away_F=Fa, away_SP=SPa, away_SN=SNa)
 
 
+def traces_512(accbpg):
+    """1000-iteration traces at the config-4 instance size (about 10 minutes of CPU)."""
+    f, h, L, x0 = accbpg.D_opt_design(512, 8192, randseed=10)
+    out = {"m": 512, "n": 8192, "seed": 10, "iters": 1000}
+    x, F, Ls, T = accbpg.BPG(f, h, L, x0, maxitrs=1000, linesearch=True, verbose=False)
+    out.update(bpgls_x=x, bpgls_F=F, bpgls_Ls=Ls)
+    x, F, G, T = accbpg.ABPG(f, h, L, x0, gamma=2.0, maxitrs=1000, theta_eq=True, verbose=False)
+    out.update(abpg_x=x, abpg_F=F, abpg_G=G)
+    x, F, Gain, Gdiv, Gavg, T = accbpg.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=300, verbose=False)
+    out.update(gain_x=x, gain_F=F, gain_Gain=Gain, gain_Gavg=Gavg)
+    save("traces_512x8192", **out)
+
+
 def next_rows(accbpg):
     """KYinit / libsvm instances, ABPG_expo, ABDA, FW_alg_div_step + lmo_simplex,
     with the calls of frank_wolfe_wtih_rs/ex_Dopt_design.py:12-21 on the housing instance and of
@@ -240,6 +253,7 @@ def main():
         housing(accbpg)
         next_rows(accbpg)
     if args.medium:
+        traces_512(accbpg)
         percall(accbpg, "512x8192", 512, 8192, 1)
         solver_traces(accbpg, "256x4096", 256, 4096, 10, 1000)
         fw_traces(accbpg, "256x4096", 256, 4096, 10, 2000)

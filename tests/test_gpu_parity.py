@@ -570,3 +570,20 @@ def test_linear_gram_reuse_matches_direct(acc, solver):
     fb, gb = f.func_grad(x0, 2)
     assert fx == fb
     np.testing.assert_array_equal(g, gb)
+
+
+def test_trajectories_512x8192(acc):
+    """1000-iteration l_inf parity at the BASELINE config-4 instance size D_opt_design(512,8192)
+    (traces from the real reference, /tmp generation script of oracle/gen_golden.py style)."""
+    gd = golden("traces_512x8192")
+    f, h, L, x0 = acc.D_opt_design(512, 8192, randseed=10)
+    x, F, Ls, T = acc.BPG(f, h, L, x0, maxitrs=1000, linesearch=True, verbose=False)
+    assert np.max(np.abs(x - gd["bpgls_x"])) < 1e-9
+    _close(F, gd["bpgls_F"], 1e-9); _close(Ls, gd["bpgls_Ls"], 1e-12)
+    x, F, G, T = acc.ABPG(f, h, L, x0, gamma=2.0, maxitrs=1000, theta_eq=True, verbose=False)
+    assert np.max(np.abs(x - gd["abpg_x"])) < 1e-9
+    _close(F, gd["abpg_F"], 1e-9)
+    x, F, Gain, Gdiv, Gavg, T = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=300, verbose=False)
+    k = _agree_prefix(Gain, gd["gain_Gain"], 1e-12)
+    assert k >= 25, k
+    _close(F[:25], gd["gain_F"][:25], 1e-9)

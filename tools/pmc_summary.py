@@ -2,7 +2,7 @@
 import csv, glob, os, sys, collections
 root = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for path in sorted(glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
+for path in sorted(glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
     with open(path) as fh:
         for row in csv.DictReader(fh):
             name = row.get("Kernel_Name", "")[:60]
