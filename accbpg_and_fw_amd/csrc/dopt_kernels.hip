@@ -105,14 +105,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_kernel(
     }
 }
 
-// grid = ntiles * T::MI: workgroup (tile, part) sums fragment row `part` of the tile's slabs, so
-// the reduction reads the slabs with MI times the workgroups (HBM-bound pass, not 72 CUs' worth)
 // Direct-to-LDS version of the Gram kernel for interior tiles (same stream-K decomposition and
 // slabs): global_load_lds_dwordx4 into three rotating swizzled stages, loads two k-steps ahead,
 // counted vmcnt + raw barrier, x applied to the A fragments after the LDS read.
 // GV (timing ablations only): bit 0 = no loads inside the k-loop, bit 1 = no wait + barrier.
-template <class T, int GV = 0>
-__global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_glds_kernel(
+// NSTAGE = 3: loads two k-steps ahead, one workgroup per CU (big tile);
+// NSTAGE = 2: loads one k-step ahead, issued right after the barrier into the buffer just read --
+//             for the mid tile at two workgroups per CU, where the co-resident workgroup hides the waits.
+template <class T, int GV = 0, int NSTAGE = 3, int WPS = 1>
+__global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
     const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n, const double* __restrict__ x,
     const TileRC* __restrict__ tiles, int ntiles, int64_t kiters, int64_t per, double* __restrict__ slabs,
     double* __restrict__ G, int64_t ldg) {
@@ -140,31 +141,56 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_glds_kernel(
             t.glds_x(x, ks * BK, st);
         };
         __builtin_amdgcn_s_barrier();                           // previous segment's readers are done
-        issue(kb, 0);
-        issue(min(kb + 1, klast), 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");   // stage 0 landed (this wave's share)
-        __builtin_amdgcn_s_barrier();
-        int cur = 0;
+        if constexpr (NSTAGE == 3) {
+            issue(kb, 0);
+            issue(min(kb + 1, klast), 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");   // stage 0 landed (this wave's share)
+            __builtin_amdgcn_s_barrier();
+            int cur = 0;
 #pragma unroll 1
-        for (int64_t ks = kb; ks < ke; ++ks) {
-            int nx2 = cur + 2;
-            if (nx2 >= 3) nx2 -= 3;
-            const double* st = lds + cur * T::G_STAGE;
-            t.template read_frag_g<0, true>(st, 0);
-            t.template read_frag_g<1, true>(st, 1);
-            t.template mma_frag<0>();
-            if constexpr (!(GV & 1)) issue(min(ks + 2, klast), nx2);   // that buffer was last read in step ks-1
-            t.template read_frag_g<0, true>(st, 2);
-            t.template mma_frag<1>();
-            t.template read_frag_g<1, true>(st, 3);
-            t.template mma_frag<0>();
-            t.template mma_frag<1>();
-            // stage ks+1 (issued one step ago) must have landed: all but the newest NLD loads done
-            if constexpr (!(GV & 2)) {
-                asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLD) : "memory");
-                __builtin_amdgcn_s_barrier();
+            for (int64_t ks = kb; ks < ke; ++ks) {
+                int nx2 = cur + 2;
+                if (nx2 >= 3) nx2 -= 3;
+                const double* st = lds + cur * T::G_STAGE;
+                t.template read_frag_g<0, true>(st, 0);
+                t.template read_frag_g<1, true>(st, 1);
+                t.template mma_frag<0>();
+                if constexpr (!(GV & 1)) issue(min(ks + 2, klast), nx2);   // that buffer was last read in step ks-1
+                t.template read_frag_g<0, true>(st, 2);
+                t.template mma_frag<1>();
+                t.template read_frag_g<1, true>(st, 3);
+                t.template mma_frag<0>();
+                t.template mma_frag<1>();
+                // stage ks+1 (issued one step ago) must have landed: all but the newest NLD loads done
+                if constexpr (!(GV & 2)) {
+                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLD) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                cur = (cur + 1 == 3) ? 0 : cur + 1;
             }
-            cur = (cur + 1 == 3) ? 0 : cur + 1;
+        } else {
+            issue(kb, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            issue(min(kb + 1, klast), 1);
+            int cur = 0;
+#pragma unroll 1
+            for (int64_t ks = kb; ks < ke; ++ks) {
+                const double* st = lds + cur * T::G_STAGE;
+                t.template read_frag_g<0, true>(st, 0);
+                t.template read_frag_g<1, true>(st, 1);
+                t.template mma_frag<0>();
+                t.template read_frag_g<0, true>(st, 2);
+                t.template mma_frag<1>();
+                t.template read_frag_g<1, true>(st, 3);
+                t.template mma_frag<0>();
+                t.template mma_frag<1>();
+                // stage ks+1 has landed and every wave is done reading stage ks ...
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                issue(min(ks + 2, klast), cur);                 // ... whose buffer takes stage ks+2
+                cur ^= 1;
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // redundant tail loads retire before LDS is reused
         if (kb == 0 && ke == kiters) {
@@ -177,6 +203,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_glds_kernel(
     }
 }
 
+// grid = ntiles * T::MI: workgroup (tile, part) sums fragment row `part` of the tile's slabs, so
+// the reduction reads the slabs with MI times the workgroups (HBM-bound pass, not 72 CUs' worth)
 template <class T>
 __global__ __launch_bounds__(NTHREADS, 2) void gram_fixup_kernel(
     const TileRC* __restrict__ tiles, int ntiles, int64_t kiters, int64_t per, const double* __restrict__ slabs,
@@ -916,8 +944,11 @@ void prof_end(accbpg_dopt* h, ProfKind k) {
 int build_plans(accbpg_dopt* h) {
     const int64_t m = h->m;
     // ---- Gram tile list (lower tiles) and stream-K partition
-    const int BM = h->big ? TileBig<false>::BM : TileSmall<false>::BM;
-    const int BN = h->big ? TileBig<false>::BN : TileSmall<false>::BN;
+    // mid tile (two workgroups per CU) for interior big problems when selected
+    const bool interior256 = h->vec_ok && (m % 256 == 0) && (h->n % BK == 0);
+    h->gram_mid = h->big && interior256 && h->want_mid;
+    const int BM = h->gram_mid ? 128 : (h->big ? TileBig<false>::BM : TileSmall<false>::BM);
+    const int BN = h->gram_mid ? 128 : (h->big ? TileBig<false>::BN : TileSmall<false>::BN);
     std::vector<TileRC> tl;
     const int nrb = (int)((m + BM - 1) / BM), ncb = (int)((m + BN - 1) / BN);
     for (int rb = 0; rb < nrb; ++rb)
@@ -926,7 +957,7 @@ int build_plans(accbpg_dopt* h) {
     h->ntiles = (int)tl.size();
     h->kiters = (h->n + BK - 1) / BK;
     const int64_t total = (int64_t)h->ntiles * h->kiters;
-    int grid = h->big ? h->num_cu : 2 * h->num_cu;
+    int grid = (h->big && !h->gram_mid) ? h->num_cu : 2 * h->num_cu;
     if (grid > total) grid = (int)total;
     if (grid < h->ntiles && total / h->ntiles < 8) grid = h->ntiles;   // tiny K: one tile per workgroup
     h->gram_per = 0;
@@ -1033,6 +1064,7 @@ int build_plans(accbpg_dopt* h) {
     ACC_TRY(set_lds(gemm_ops_kernel<TileSmall<false>>, TileSmall<false>::LDS_BYTES));
     ACC_TRY(set_lds(chol_step_kernel, CHOL_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>>, TileBig<false, false>::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<TileMid<false, false>, 0, 2, 2>, 2 * TileMid<false, false>::G_STAGE * 8));
     ACC_TRY(set_lds(colnorm_glds_kernel<TileBig<true, false>>, TileBig<true, false>::G_LDS_BYTES + 4 * 128 * 8));
     ACC_TRY(set_lds(gemm_big_kernel<TileBig<true>>, TileBig<true>::LDS_BYTES));
     ACC_TRY(set_lds(gemm_big_kernel<TileBig<false>>, TileBig<false>::LDS_BYTES));
@@ -1112,6 +1144,19 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
 
 int launch_gram(accbpg_dopt* h, const double* x, double* gram) {
     const bool xal = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (h->gram_mid && xal) {
+        using T = TileMid<false, false>;
+        prof_begin(h, PROF_GRAM);
+        gram_streamk_glds_kernel<T, 0, 2, 2><<<h->gram_grid, NTHREADS, 2 * T::G_STAGE * 8, h->stream>>>(
+            h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->slabs, gram, h->m);
+        prof_end(h, PROF_GRAM);
+        prof_begin(h, PROF_GRAMFIX);
+        gram_fixup_kernel<T><<<h->ntiles * T::MI, NTHREADS, 0, h->stream>>>(h->tiles, h->ntiles, h->kiters,
+                                                                            h->gram_per, h->slabs, gram, h->m, h->m);
+        prof_end(h, PROF_GRAMFIX);
+        ACC_HIP(hipGetLastError());
+        return ACCBPG_OK;
+    }
     if (h->big) {
         const bool interior = h->vec_ok && xal && (h->m % 256 == 0) && (h->n % BK == 0);
         if (interior) gram_launch_t<TileBig<false, false>>(h, x, gram);
