@@ -7,6 +7,8 @@
 //   :48  np.linalg.slogdet           -> Cholesky (potrf_diag / trsm_panel / trailing GEMM), logdet = 2*sum log L_ii
 //   :57  np.linalg.solve(HXHT, H)    -> W = L^-1 (trtri_diag + merge GEMMs), Y = W V never stored
 //   :58  -sum(H * HXHTinvH, axis=0)  -> -colsum(Y*Y) fused into the product (colnorm_kernel)
+#include <type_traits>
+
 #include "internal.h"
 #include "mfma_tile.hpp"
 
@@ -637,8 +639,11 @@ __device__ __forceinline__ void potrf64_lds(const double* __restrict__ S, double
     // each row keeps its pivot value and takes the root after the loop.
     double* junk = colbuf + 2 * NB;                               // NB doubles nobody relies on
     double dsave = 1.0;
-#pragma unroll 1
-    for (int cg = 0; cg < NB / 4; ++cg) {
+    // `live` registers (columns still to the right) shrink by one per group of four columns; the
+    // loop is cut into four chunks with compile-time bounds 16/12/8/4 so finished registers cost
+    // neither LDS reads nor FMAs (the step is bound by its LDS instruction volume).
+    auto group = [&](int cg, auto live_tag) {
+        constexpr int LIVE = decltype(live_tag)::value;
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci) {
             const int c = 4 * cg + ci;
@@ -647,23 +652,28 @@ __device__ __forceinline__ void potrf64_lds(const double* __restrict__ S, double
             const double rp = pvbuf[par];
             const double arc = col[r];
             const double* colq = col + 4 * cg + q;
-            double cv[NB / 4];
+            double cv[LIVE];
 #pragma unroll
-            for (int t = 0; t < NB / 4; ++t) cv[t] = colq[4 * t];   // one batch of independent reads (pad past 63)
+            for (int t = 0; t < LIVE; ++t) cv[t] = colq[4 * t];   // one batch of independent reads
             const double lrc = arc * rp;                          // row c itself: d * 1/sqrt(d) ~ sqrt(d), fixed below
             dsave = (r == c) ? arc : dsave;
             const double w = lrc * rp;
             // column c+1 lives in a[0] of wave ci+1, or (ci == 3) in a[1] of wave 0
             const int qn = (ci + 1) & 3;
             const int tn = (ci == 3) ? 1 : 0;
-            a[tn] = fma(-w, cv[tn], a[tn]);                       // heads the dependent chain
+            if constexpr (LIVE > 1) {
+                a[tn] = fma(-w, cv[tn], a[tn]);                   // heads the dependent chain
+            } else {
+                if (tn == 0) a[0] = fma(-w, cv[0], a[0]);
+            }
+            const double anext = (LIVE > 1 || tn == 0) ? a[(LIVE > 1) ? tn : 0] : 1.0;
             const bool own_next = (q == qn);
             {
                 double* dst = own_next ? (colbuf + (par ^ 1) * NB + r) : (junk + r);
-                *dst = a[tn];
+                *dst = anext;
                 const bool is_piv = own_next && (r == c + 1);
-                const bool nonpos = !(a[tn] > 0.0);
-                const double rpn = rsqrt_newton(fmax(a[tn], 1e-300));
+                const bool nonpos = !(anext > 0.0);
+                const double rpn = rsqrt_newton(fmax(anext, 1e-300));
                 double* pdst = is_piv ? (pvbuf + (par ^ 1)) : (junk + (r & 31));
                 *pdst = rpn;
                 int* bdst = (is_piv && nonpos && c + 1 < bs) ? badflag : reinterpret_cast<int*>(junk + NB - 2);
@@ -674,14 +684,22 @@ __device__ __forceinline__ void potrf64_lds(const double* __restrict__ S, double
                 *ldst = (r >= c) ? lrc : 0.0;
             }
 #pragma unroll
-            for (int t = 0; t < NB / 4; ++t)
+            for (int t = 0; t < LIVE; ++t)
                 if (t != tn) a[t] = fma(-w, cv[t], a[t]);
             __syncthreads();
         }
 #pragma unroll
         for (int t = 0; t + 1 < NB / 4; ++t) a[t] = a[t + 1];
         a[NB / 4 - 1] = 0.0;
-    }
+    };
+#pragma unroll 1
+    for (int cg = 0; cg < 4; ++cg) group(cg, std::integral_constant<int, 16>{});
+#pragma unroll 1
+    for (int cg = 4; cg < 8; ++cg) group(cg, std::integral_constant<int, 12>{});
+#pragma unroll 1
+    for (int cg = 8; cg < 12; ++cg) group(cg, std::integral_constant<int, 8>{});
+#pragma unroll 1
+    for (int cg = 12; cg < 16; ++cg) group(cg, std::integral_constant<int, 4>{});
     // diagonal: L[r][r] = sqrt(pivot value of row r) (rows >= bs hold the identity padding: 1)
     if (q == 0) Lo[r * SP + r] = sqrt(dsave);
     __syncthreads();
@@ -698,19 +716,20 @@ __device__ __forceinline__ void trsm64_lds(double* __restrict__ Xs, const double
     double p[NB / 4];
 #pragma unroll
     for (int t = 0; t < NB / 4; ++t) p[t] = Xs[row * SP + 4 * t + q];
-#pragma unroll 1
-    for (int cg = 0; cg < NB / 4; ++cg) {
-        // rows (4cg+q+4t) of L, wrapped into 0..63 for the registers already past column 63 (dead)
-        const double* lrow[NB / 4];
+    auto group = [&](int cg, auto live_tag) {
+        constexpr int LIVE = decltype(live_tag)::value;         // registers whose column is <= 63
+        // rows (4cg+q+4t) of L for the live registers (wrapped into 0..63 where a chunk's bound still
+        // covers a register that has already moved past column 63)
+        const double* lrow[LIVE];
 #pragma unroll
-        for (int t = 0; t < NB / 4; ++t) lrow[t] = Lo + ((4 * cg + q + 4 * t) & (NB - 1)) * SP + 4 * cg;
+        for (int t = 0; t < LIVE; ++t) lrow[t] = Lo + ((4 * cg + q + 4 * t) & (NB - 1)) * SP + 4 * cg;
         double xc[4];
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci) {
             const int c = 4 * cg + ci;
-            double lv[NB / 4];
+            double lv[LIVE];
 #pragma unroll
-            for (int t = 0; t < NB / 4; ++t) lv[t] = lrow[t][ci];   // independent of the solve chain
+            for (int t = 0; t < LIVE; ++t) lv[t] = lrow[t][ci];   // independent of the solve chain
             const double mine = p[0] * rinv[c];
             double x;
             if (ci == 0) x = quad_bcast<0>(mine);
@@ -719,7 +738,7 @@ __device__ __forceinline__ void trsm64_lds(double* __restrict__ Xs, const double
             else x = quad_bcast<3>(mine);
             xc[ci] = x;
 #pragma unroll
-            for (int t = 0; t < NB / 4; ++t) p[t] = fma(-x, lv[t], p[t]);
+            for (int t = 0; t < LIVE; ++t) p[t] = fma(-x, lv[t], p[t]);
         }
         if (q == 0) Xs[row * SP + 4 * cg + 0] = xc[0];
         if (q == 1) Xs[row * SP + 4 * cg + 1] = xc[1];
@@ -728,11 +747,17 @@ __device__ __forceinline__ void trsm64_lds(double* __restrict__ Xs, const double
 #pragma unroll
         for (int t = 0; t + 1 < NB / 4; ++t) p[t] = p[t + 1];
         p[NB / 4 - 1] = 0.0;
-    }
+    };
+#pragma unroll 1
+    for (int cg = 0; cg < 4; ++cg) group(cg, std::integral_constant<int, 16>{});
+#pragma unroll 1
+    for (int cg = 4; cg < 8; ++cg) group(cg, std::integral_constant<int, 12>{});
+#pragma unroll 1
+    for (int cg = 8; cg < 12; ++cg) group(cg, std::integral_constant<int, 8>{});
+#pragma unroll 1
+    for (int cg = 12; cg < 16; ++cg) group(cg, std::integral_constant<int, 4>{});
 }
 
-// dbg (timing ablations only, wrong results unless 0): bit 0 skips the factorisation of the diagonal
-// block, bit 1 the panel solve, bit 2 the MFMA products.
 __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restrict__ A, int64_t lda, int64_t m,
                                                                int kprev, int T, double* __restrict__ logdet,
                                                                int* __restrict__ flags, int dbg) {
