@@ -31,6 +31,8 @@ _SIGS = {
     "accbpg_dopt_destroy": (C.c_int, [_P]),
     "accbpg_dopt_set_stream": (C.c_int, [_P, _P]),
     "accbpg_dopt_func_grad": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_double), _P]),
+    "accbpg_dopt_func_grad_begin": (C.c_int, [_P, _P, C.c_int, _P]),
+    "accbpg_dopt_func_grad_end": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "accbpg_dopt_gram": (C.c_int, [_P, _P, _P]),
     "accbpg_dopt_factor": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),
     "accbpg_dopt_grad": (C.c_int, [_P, _P]),

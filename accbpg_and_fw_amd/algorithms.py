@@ -34,6 +34,19 @@ def _value(f, x, combo=None):
     return f.func_grad_combo(x, combo, 0) if _lin(f) else f(x)
 
 
+def _value_begin(f, x, combo):
+    """F[k] = f(x) does not feed the gradient evaluation at y: when the objective has overlapping
+    switched on (DOptimalObj.overlap_values) it is started on the side stream, otherwise evaluated now."""
+    if (not _lin(f)) and getattr(f, "_overlap", False) and isinstance(x, torch.Tensor) and x.is_cuda:
+        return ("ticket", f.value_async(x))
+    return ("value", _value(f, x, combo))
+
+
+def _value_end(f, pending):
+    kind, payload = pending
+    return f.value_wait(payload) if kind == "ticket" else payload
+
+
 def _drain(gen):
     """Run a step generator to completion and return its result."""
     while True:
@@ -140,8 +153,7 @@ def ABPG_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=False,
     xcombo = None
     k = -1
     for k in range(maxitrs):
-        F[k] = _value(f, x, xcombo) + h.extra_Psi(x)            # :135-136
-        T[k] = time.time() - t_start
+        pending = _value_begin(f, x, xcombo)                    # :135 (runs beside the gradient below)
 
         z_prev, x_prev = z, x
         if theta_eq and kk > 0:                                 # :142-145
@@ -154,6 +166,8 @@ def ABPG_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=False,
             g = f.func_grad_combo(y, (1 - theta, x_prev, theta, z_prev), 1)
         else:
             g = f.gradient(y)                                   # :148
+        F[k] = _value_end(f, pending) + h.extra_Psi(x_prev)     # :136
+        T[k] = time.time() - t_start
         z = h.div_prox_map(z_prev, g, theta ** (gamma - 1) * L)  # :149
         x = vec_axpby(1 - theta, x, theta, z)                   # :150
         if _lin(f):
@@ -224,8 +238,7 @@ def ABPG_gain_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, G0=1,
     xcombo = None
     k = -1
     for k in range(maxitrs):
-        F[k] = _value(f, x, xcombo) + h.extra_Psi(x)            # :347-348
-        T[k] = time.time() - t_start
+        pending = _value_begin(f, x, xcombo)                    # :347 (runs beside the first gradient below)
 
         z_prev, x_prev = z, x
         G_prev, theta_prev = G, theta
@@ -245,6 +258,10 @@ def ABPG_gain_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, G0=1,
                 fy, g = f.func_grad_combo(y, (1 - theta, x_prev, theta, z_prev), 2)
             else:
                 fy, g = f.func_grad(y)                          # :371
+            if pending is not None:
+                F[k] = _value_end(f, pending) + h.extra_Psi(x_prev)   # :348
+                T[k] = time.time() - t_start
+                pending = None
             z = h.div_prox_map(z_prev, g, theta ** (gamma - 1) * G * L)   # :373
             x = vec_axpby(1 - theta, x_prev, theta, z)          # :374
             if _lin(f):

@@ -126,18 +126,28 @@ extern "C" int accbpg_dopt_grad(accbpg_dopt* h, double* g_dev) {
     return ACCBPG_OK;
 }
 
-extern "C" int accbpg_dopt_func_grad(accbpg_dopt* h, const double* x_dev, int flag, double* f_host, double* g_dev) {
+/* Enqueue a whole func_grad on the handle's stream without waiting: Gram, Cholesky, (gradient),
+ * and the copy of the scalars / flags to the pinned mirror.  accbpg_dopt_func_grad_end waits for it.
+ * Two handles on the same V with different streams let independent evaluations overlap (the
+ * latency-bound factorisation of one under the MFMA-bound products of the other). */
+extern "C" int accbpg_dopt_func_grad_begin(accbpg_dopt* h, const double* x_dev, int flag, double* g_dev) {
     if (!h || !x_dev || flag < 0 || flag > 2) return ACCBPG_ERR_ARG;
     if (flag != 0 && !g_dev) return ACCBPG_ERR_ARG;
     ACC_TRY(launch_gram(h, x_dev, h->Lbuf));
     ACC_TRY(launch_cholesky(h, h->Lbuf));                       // resets the flags first
     check_nonneg_kernel<<<64, 256, 0, h->stream>>>(x_dev, h->n, h->dflag);      // functions.py:45
     if (flag != 0) {
-        // gradient work is queued before the status readback so the host never idles the GPU
         ACC_TRY(launch_trtri(h));
         ACC_TRY(launch_colnorm(h, h->Wbuf, g_dev, -1.0));
     }
-    ACC_TRY(read_status(h));
+    ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
+    ACC_HIP(hipMemcpyAsync(h->hpin + 16, h->dflag, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_dopt_func_grad_end(accbpg_dopt* h, double* f_host) {
+    if (!h) return ACCBPG_ERR_ARG;
+    ACC_HIP(hipStreamSynchronize(h->stream));
     const int* fl = reinterpret_cast<const int*>(h->hpin + 16);
     if (fl[FLAG_NEG_X]) {
         set_last_error("DOptimalObj: x needs to be nonnegative");
@@ -149,6 +159,11 @@ extern "C" int accbpg_dopt_func_grad(accbpg_dopt* h, const double* x_dev, int fl
     }
     if (f_host) *f_host = -h->hpin[0];
     return ACCBPG_OK;
+}
+
+extern "C" int accbpg_dopt_func_grad(accbpg_dopt* h, const double* x_dev, int flag, double* f_host, double* g_dev) {
+    ACC_TRY(accbpg_dopt_func_grad_begin(h, x_dev, flag, g_dev));
+    return accbpg_dopt_func_grad_end(h, f_host);
 }
 
 namespace accbpg {

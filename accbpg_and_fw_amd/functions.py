@@ -104,6 +104,7 @@ class DOptimalObj(RSmoothFunction):
         self._lib = lib
         self.calls = {"value": 0, "grad": 0}
         # opt-in reuse of resident Gram matrices through linearity (see linear_gram())
+        self._overlap = False
         self._lin = False
         self._gcache = []           # [(vector tensor, Gram tensor, age)], most recent last
         self._gcache_cap = 5
@@ -113,13 +114,50 @@ class DOptimalObj(RSmoothFunction):
         self.value_hits = 0
 
     def __del__(self):
-        h = getattr(self, "_h", None)
-        if h:
-            try:
-                self._lib.accbpg_dopt_destroy(h)
-            except Exception:
-                pass
-            self._h = None
+        for name in ("_h", "_h2"):
+            h = getattr(self, name, None)
+            if h:
+                try:
+                    self._lib.accbpg_dopt_destroy(h)
+                except Exception:
+                    pass
+                setattr(self, name, None)
+
+    # ---- a value evaluation that runs beside other work (second handle, second stream) ----
+    def overlap_values(self, enable=True):
+        """Opt-in: let the accelerated solvers run F[k] = f(x) on a side stream beside the gradient
+        evaluation at y (independent of it).  Identical kernels and results; off by default so that
+        per-kernel timings stay uncontended."""
+        self._overlap = bool(enable)
+        return self
+
+    def value_async(self, x):
+        """Start f(x) on a side stream and return a ticket for ``value_wait``.  The accelerated
+        solvers use it for F[k] = f(x), which the gradient evaluation at y does not depend on, so the
+        latency-bound factorisation of one evaluation runs under the MFMA-bound products of the
+        other.  Same kernels, same results as ``f(x)``."""
+        assert x.numel() == self.n, "DOptimalObj: x.size not equal to n"
+        if getattr(self, "_h2", None) is None:
+            h2 = C.c_void_p()
+            with torch.cuda.device(self._V.device):
+                self._side = torch.cuda.Stream(device=self._V.device)
+                rc = self._lib.accbpg_dopt_create(_ptr(self._V), self.m, self.n, self._V.stride(0),
+                                                  C.c_void_p(self._side.cuda_stream), C.byref(h2), 1)
+            _lib.check(rc, "accbpg_dopt_create")
+            self._h2 = h2
+        with torch.cuda.device(self._V.device):
+            self._side.wait_stream(torch.cuda.current_stream())          # x is produced on the caller's stream
+            rc = self._lib.accbpg_dopt_func_grad_begin(self._h2, _ptr(x), 0, None)
+        _lib.check(rc, "accbpg_dopt_func_grad_begin")
+        return x                                                          # the ticket keeps x alive
+
+    def value_wait(self, ticket):
+        fval = C.c_double(0.0)
+        with torch.cuda.device(self._V.device):
+            rc = self._lib.accbpg_dopt_func_grad_end(self._h2, C.byref(fval))
+        _lib.check(rc, "accbpg_dopt_func_grad_end", "DOptimalObj: x needs to be nonnegative")
+        self.calls["value"] += 1
+        return fval.value
 
     @property
     def device(self):

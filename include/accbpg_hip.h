@@ -59,6 +59,13 @@ int accbpg_dopt_set_stream(accbpg_dopt* h, void* stream);
 int accbpg_dopt_func_grad(accbpg_dopt* h, const double* x_dev, int flag,
                           double* f_host, double* g_dev);
 
+/* func_grad split into enqueue / wait.  `begin` queues the whole evaluation on the handle's stream
+ * and returns; `end` waits for it and reports f and the status.  Two handles on the same V with
+ * different streams let INDEPENDENT evaluations overlap -- e.g. F[k] = f(x) and func_grad(y) of the
+ * accelerated methods (accbpg/algorithms.py:135 and :148, :347 and :371; y does not depend on f(x)). */
+int accbpg_dopt_func_grad_begin(accbpg_dopt* h, const double* x_dev, int flag, double* g_dev);
+int accbpg_dopt_func_grad_end(accbpg_dopt* h, double* f_host);
+
 /* The same computation in three stages, for design-point sharding across GPUs
  * (SURVEY.md 8(e).2): each rank forms its local Gram contribution, the caller all-reduces
  * gram_dev (m*m doubles, lower triangle significant) over RCCL, every rank factors it and

@@ -587,3 +587,24 @@ def test_trajectories_512x8192(acc):
     k = _agree_prefix(Gain, gd["gain_Gain"], 1e-12)
     assert k >= 25, k
     _close(F[:25], gd["gain_F"][:25], 1e-9)
+
+
+def test_overlapped_value_evaluation_is_identical(acc):
+    """Opt-in: F[k] = f(x) on a side stream beside func_grad(y).  Same kernels on the same data, so
+    the whole run is bitwise identical to the sequential one."""
+    f, h, L, x0 = acc.D_opt_design(300, 3000, randseed=21)
+    a = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=60, verbose=False)
+    b = acc.ABPG(f, h, L, x0, gamma=2.0, maxitrs=60, theta_eq=True, restart=True, verbose=False)
+    f.overlap_values(True)
+    a2 = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=60, verbose=False)
+    b2 = acc.ABPG(f, h, L, x0, gamma=2.0, maxitrs=60, theta_eq=True, restart=True, verbose=False)
+    f.overlap_values(False)
+    for u, v in [(a, a2), (b, b2)]:
+        for p, q in zip(u[:-1], v[:-1]):
+            np.testing.assert_array_equal(p, q)
+    # an error inside the overlapped evaluation surfaces at the wait
+    f.overlap_values(True)
+    bad = torch.from_numpy(-x0).cuda()
+    with pytest.raises(AssertionError):
+        f.value_wait(f.value_async(bad))
+    f.overlap_values(False)
