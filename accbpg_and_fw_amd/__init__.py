@@ -9,16 +9,17 @@ kernel, and D_opt_FW / D_opt_FW_away, behind the reference's own names and signa
 All arithmetic runs in hand-written gfx950 HIP kernels (accbpg_and_fw_amd/csrc) through a
 ctypes C-ABI (include/accbpg_hip.h); there is no CPU fallback.
 """
-from .functions import (RSmoothFunction, DOptimalObj, LegendreFunction, BurgEntropy,
-                        BurgEntropySimplex)
+from .functions import (RSmoothFunction, DOptimalObj, PoissonRegression, LegendreFunction, BurgEntropy,
+                        BurgEntropyL1, BurgEntropyL2, BurgEntropySimplex)
 from .algorithms import BPG, ABPG, ABPG_gain, ABPG_expo, ABDA, solve_theta
 from .algorithms_fw import FW_alg_div_step
 from .functions_lmo import lmo_simplex
 from .D_opt_alg import D_opt_FW, D_opt_FW_away
-from .applications import D_opt_design, D_opt_libsvm, D_opt_KYinit
+from .applications import D_opt_design, D_opt_libsvm, D_opt_KYinit, Poisson_regrL1, Poisson_regrL2
 from .utils import load_libsvm_file
 
-__all__ = ["RSmoothFunction", "DOptimalObj", "LegendreFunction", "BurgEntropy", "BurgEntropySimplex",
+__all__ = ["RSmoothFunction", "DOptimalObj", "PoissonRegression", "LegendreFunction", "BurgEntropy",
+           "BurgEntropyL1", "BurgEntropyL2", "BurgEntropySimplex", "Poisson_regrL1", "Poisson_regrL2",
            "BPG", "ABPG", "ABPG_gain", "ABPG_expo", "ABDA", "solve_theta", "FW_alg_div_step", "lmo_simplex",
            "D_opt_FW", "D_opt_FW_away", "D_opt_design", "D_opt_libsvm", "D_opt_KYinit", "load_libsvm_file"]
 __version__ = "0.1.0"

@@ -55,6 +55,13 @@ _SIGS = {
     "accbpg_fw_probe_step": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FwProbe)]),
     "accbpg_fw_update": (C.c_int, [_P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double]),
     "accbpg_fw_get_state": (C.c_int, [_P, _P, _P, _P]),
+    "accbpg_poisson_create": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _P, _P, C.POINTER(_P)]),
+    "accbpg_poisson_destroy": (C.c_int, [_P]),
+    "accbpg_poisson_set_stream": (C.c_int, [_P, _P]),
+    "accbpg_poisson_func_grad": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_double), _P]),
+    "accbpg_poisson_get_ax": (C.c_int, [_P, _P]),
+    "accbpg_burg_reg_div_prox": (C.c_int, [C.c_int, _P, _P, C.c_double, C.c_double, C.c_int64, _P, _P]),
+    "accbpg_vec_dot": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_double), _P, _P]),
     "accbpg_dopt_profile_enable": (C.c_int, [_P, C.c_int]),
     "accbpg_dopt_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "accbpg_dopt_profile_reset": (C.c_int, [_P]),

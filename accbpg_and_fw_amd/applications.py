@@ -3,7 +3,8 @@ from __future__ import annotations
 
 import numpy as np
 
-from .functions import BurgEntropySimplex, DOptimalObj, vec_argminmax
+from .functions import (BurgEntropyL1, BurgEntropyL2, BurgEntropySimplex, DOptimalObj, PoissonRegression,
+                        vec_argminmax)
 from .utils import load_libsvm_file
 
 
@@ -71,3 +72,33 @@ def D_opt_design(m, n, randseed=-1):
     L = 1.0
     x0 = (1.0 / n) * np.ones(n)
     return f, h, L, x0
+
+
+def _poisson_instance(m, n, noise, randseed, normalizeA):
+    """(A, b) of the random Poisson linear inverse problem (accbpg/applications.py:114-123, 153-162):
+    legacy global RNG drawn in the order A, x, noise; generated on the host like the reference's."""
+    if randseed > 0:
+        np.random.seed(randseed)
+    A = np.random.rand(m, n)
+    if normalizeA:
+        A = A / A.sum(axis=0)
+    x = np.random.rand(n) / n
+    xavg = x.sum() / x.size
+    x = np.maximum(x - xavg, 0) * 10
+    b = np.dot(A, x) + noise * (np.random.rand(m) - 0.5)
+    assert b.min() > 0, "need b > 0 for nonnegative regression."
+    return A, b
+
+
+def Poisson_regrL1(m, n, noise=0.01, lamda=0, randseed=-1, normalizeA=True):
+    """minimize_{x >= 0} D_KL(b, Ax) + lamda*||x||_1  (accbpg/applications.py:98-133).
+    Returns f, h, L = ||b||_1, x0 = (10/n)*ones."""
+    A, b = _poisson_instance(m, n, noise, randseed, normalizeA)
+    return PoissonRegression(A, b), BurgEntropyL1(lamda), b.sum(), (1.0 / n) * np.ones(n) * 10
+
+
+def Poisson_regrL2(m, n, noise=0.01, lamda=0, randseed=-1, normalizeA=True):
+    """minimize_{x >= 0} D_KL(b, Ax) + (lamda/2)*||x||_2^2  (accbpg/applications.py:136-172).
+    Returns f, h, L = ||b||_1, x0 = (1/n)*ones."""
+    A, b = _poisson_instance(m, n, noise, randseed, normalizeA)
+    return PoissonRegression(A, b), BurgEntropyL2(lamda), b.sum(), (1.0 / n) * np.ones(n)

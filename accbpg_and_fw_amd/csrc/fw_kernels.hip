@@ -239,14 +239,8 @@ static int fw_alloc(accbpg_dopt* h) {
     return ACCBPG_OK;
 }
 
-static int fw_nsplit(const accbpg_dopt* h) {
-    const int64_t colblocks = (h->n + VG_COLS - 1) / VG_COLS;
-    int64_t s = (4 * (int64_t)h->num_cu + colblocks - 1) / colblocks;
-    if (s > VG_MAXSPLIT) s = VG_MAXSPLIT;
-    if (s > h->m / 8) s = h->m / 8;
-    if (s < 1) s = 1;
-    return (int)s;
-}
+namespace accbpg { int vt_nsplit(int64_t m, int64_t n, int num_cu); }
+static int fw_nsplit(const accbpg_dopt* h) { return vt_nsplit(h->m, h->n, h->num_cu); }
 
 static int read_scalars(accbpg_dopt* h, int nd, int ni) {
     ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * nd, hipMemcpyDeviceToHost, h->stream));
@@ -347,18 +341,33 @@ extern "C" int accbpg_fw_get_state(accbpg_dopt* h, double* x_dev, double* w_dev,
     return ACCBPG_OK;
 }
 
+namespace accbpg {
+int vt_nsplit(int64_t m, int64_t n, int num_cu) {
+    const int64_t colblocks = (n + VG_COLS - 1) / VG_COLS;
+    int64_t s = (4 * (int64_t)num_cu + colblocks - 1) / colblocks;
+    if (s > VG_MAXSPLIT) s = VG_MAXSPLIT;
+    if (s > m / 8) s = m / 8;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+// u = V^T q for a row-major m x n matrix: split-row partial sums into upart (nsplit*n doubles), then their sum
+int launch_vt_times(const double* V, int64_t ldv, int64_t m, int64_t n, const double* q, double* upart, int nsplit,
+                    double* u, bool vec_ok, hipStream_t s) {
+    dim3 vg((unsigned)((n + VG_COLS - 1) / VG_COLS), (unsigned)nsplit);
+    fw_vgemv_partial_kernel<<<vg, FB, 0, s>>>(V, ldv, m, n, q, nsplit, upart, vec_ok);
+    int64_t wb = (n + FB - 1) / FB;
+    if (wb > 2048) wb = 2048;
+    fw_usum_kernel<<<(int)wb, FB, 0, s>>>(upart, nsplit, n, u);
+    ACC_HIP(hipGetLastError());
+    return ACCBPG_OK;
+}
+}  // namespace accbpg
+
 /* u = V^T q  (np.dot(q, V), applications.py:79): one pass over V on the split-row kernel */
 extern "C" int accbpg_dopt_vt_times(accbpg_dopt* h, const double* q_dev, double* u_dev) {
     if (!h || !q_dev || !u_dev) return ACCBPG_ERR_ARG;
-    const int64_t m = h->m, n = h->n;
-    const int ns = fw_nsplit(h);
-    dim3 vg((unsigned)((n + VG_COLS - 1) / VG_COLS), (unsigned)ns);
-    fw_vgemv_partial_kernel<<<vg, FB, 0, h->stream>>>(h->V, h->ldv, m, n, q_dev, ns, h->vws, h->vec_ok);
-    int64_t wb = (n + FB - 1) / FB;
-    if (wb > 2048) wb = 2048;
-    fw_usum_kernel<<<(int)wb, FB, 0, h->stream>>>(h->vws, ns, n, u_dev);
-    ACC_HIP(hipGetLastError());
-    return ACCBPG_OK;
+    return launch_vt_times(h->V, h->ldv, h->m, h->n, q_dev, h->vws, fw_nsplit(h), u_dev, h->vec_ok, h->stream);
 }
 
 extern "C" int accbpg_dopt_get_column(accbpg_dopt* h, int64_t j, double* out_dev) {

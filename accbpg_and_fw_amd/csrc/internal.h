@@ -46,6 +46,7 @@ constexpr int NB = 64;          // Cholesky / inverse block size
 constexpr int FLAG_NOT_PD = 0;  // index into the device flag array
 constexpr int FLAG_NEG_X = 1;
 constexpr int FLAG_NONPOS = 2;
+constexpr int FLAG_BAD_G = 3;
 
 enum ProfKind { PROF_GRAM = 0, PROF_CHOL = 1, PROF_TRTRI = 2, PROF_GRAD = 3, PROF_GRAMFIX = 4, PROF_COUNT = 5 };
 
@@ -114,6 +115,12 @@ int mfma_peak(int iters, double* tflops, hipStream_t s);
 
 // vec_kernels.hip
 int64_t vec_ws_doubles(int64_t n);
+
+// fw_kernels.hip
+int vt_nsplit(int64_t m, int64_t n, int num_cu);
+int launch_vt_times(const double* V, int64_t ldv, int64_t m, int64_t n, const double* q, double* upart, int nsplit,
+                    double* u, bool vec_ok, hipStream_t s);
+constexpr int VT_MAXSPLIT = 64;
 
 // prof helpers
 void prof_begin(accbpg_dopt* h, ProfKind k);

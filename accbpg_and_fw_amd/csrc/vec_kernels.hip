@@ -264,6 +264,65 @@ __global__ __launch_bounds__(RB) void vertex_kernel(int64_t idx, double value, d
     for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) out[i] = (i == idx) ? value : fill;
 }
 
+// sum x*y  (np.dot(x, x) of BurgEntropyL2.extra_Psi, functions.py:314)
+__global__ __launch_bounds__(RB) void dot_partial_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                                        int64_t n, double* __restrict__ part) {
+    __shared__ double sh[RB / 64];
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * RB;
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) s += x[i] * y[i];
+    s = wave_sum(s);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0;
+        for (int i = 0; i < RB / 64; ++i) a += sh[i];
+        part[blockIdx.x * 4 + 0] = a; part[blockIdx.x * 4 + 1] = 0.0;
+        part[blockIdx.x * 4 + 2] = 0.0; part[blockIdx.x * 4 + 3] = 0.0;
+    }
+}
+
+// Closed-form Burg-entropy prox maps on x > 0 with NumPy's operation order:
+//   gt = g - L*(-1/y)  when y != NULL (BurgEntropy.div_prox_map, functions.py:264-271), else gt = g
+//   kind 0: L / gt                                     (BurgEntropy.prox_map,   :255-262, needs gt > 0)
+//   kind 1: L / (lamda + gt)                           (BurgEntropyL1.prox_map, :290-298, needs gt > -lamda)
+//   kind 2: (sqrt(gg*gg + 4*lamda_L) - gg)/(2*lamda_L) (BurgEntropyL2.prox_map, :316-323), gg = gt/L, lamda_L = lamda/L
+__global__ __launch_bounds__(RB) void burg_reg_prox_kernel(int kind, const double* __restrict__ y,
+                                                          const double* __restrict__ g, double L, double lamda,
+                                                          int64_t n, double* __restrict__ out,
+                                                          int* __restrict__ flags) {
+    const int64_t stride = (int64_t)gridDim.x * RB;
+    const double lamda_L = lamda / L;
+    const double four_l = 4 * lamda_L, two_l = 2 * lamda_L;
+    bool bad_y = false, bad_g = false;
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
+        double gt = g[i];
+        if (y != nullptr) {
+            const double yi = y[i];
+            bad_y |= !(yi > 0.0);
+            const double hy = -1.0 / yi;
+            const double t = L * hy;
+            gt = gt - t;
+        }
+        double r;
+        if (kind == 0) {
+            bad_g |= !(gt > 0.0);
+            r = L / gt;
+        } else if (kind == 1) {
+            bad_g |= !(gt > -lamda);
+            r = L / (lamda + gt);
+        } else {
+            const double gg = gt / L;
+            const double sq = gg * gg;
+            r = (sqrt(sq + four_l) - gg) / two_l;
+        }
+        out[i] = r;
+    }
+    if (bad_y) flags[FLAG_NONPOS] = 1;
+    if (bad_g) flags[FLAG_BAD_G] = 1;
+}
+
 struct MinMaxRec {
     double vmin, vmax;
     int64_t imin, imax;
@@ -477,5 +536,50 @@ extern "C" int accbpg_vec_argminmax(const double* x_dev, int64_t n, int64_t* idx
     idx_host[0] = r->imin;
     idx_host[1] = r->imax;
     if (val_host) { val_host[0] = r->vmin; val_host[1] = r->vmax; }
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_vec_dot(const double* x_dev, const double* y_dev, int64_t n, double* out_host, double* ws_dev,
+                              void* stream) {
+    if (!x_dev || !y_dev || n <= 0 || !out_host || !ws_dev) return ACCBPG_ERR_ARG;
+    ACC_TRY(ensure_scratch());
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = red_blocks(n);
+    double* part = ws_dev + n;
+    dot_partial_kernel<<<nb, RB, 0, s>>>(x_dev, y_dev, n, part);
+    ls_terms_final_kernel<<<1, RB, 0, s>>>(part, nb, g_out);
+    ACC_HIP(hipGetLastError());
+    ACC_HIP(hipMemcpyAsync(g_pin + 8, g_out, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+    ACC_HIP(hipStreamSynchronize(s));
+    out_host[0] = g_pin[8];
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_burg_reg_div_prox(int kind, const double* y_dev, const double* g_dev, double L, double lamda,
+                                        int64_t n, double* x_out_dev, void* stream) {
+    if (!g_dev || !x_out_dev || n <= 0 || kind < 0 || kind > 2) return ACCBPG_ERR_ARG;
+    if (!(L > 0.0)) {                                           // functions.py:260, :270, :295, :320
+        set_last_error("prox_map only takes positive L");
+        return ACCBPG_ERR_ASSERT;
+    }
+    if (kind != 0 && !(lamda >= 0.0)) return ACCBPG_ERR_ARG;
+    ACC_TRY(ensure_scratch());
+    hipStream_t s = (hipStream_t)stream;
+    ACC_HIP(hipMemsetAsync(g_flags, 0, 8 * sizeof(int), s));
+    int64_t nb = (n + RB - 1) / RB;
+    if (nb > 2048) nb = 2048;
+    burg_reg_prox_kernel<<<(int)nb, RB, 0, s>>>(kind, y_dev, g_dev, L, lamda, n, x_out_dev, g_flags);
+    ACC_HIP(hipGetLastError());
+    int* pin_i = reinterpret_cast<int*>(g_pin);
+    ACC_HIP(hipMemcpyAsync(pin_i, g_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    ACC_HIP(hipStreamSynchronize(s));
+    if (pin_i[FLAG_NONPOS]) {                                   // y.min() > 0, functions.py:270
+        set_last_error("Either y or L is not positive.");
+        return ACCBPG_ERR_ASSERT;
+    }
+    if (pin_i[FLAG_BAD_G]) {                                    // functions.py:261 / :296
+        set_last_error(kind == 1 ? "Not getting positive solution." : "BurgEntropy prox_map only takes positive value.");
+        return ACCBPG_ERR_ASSERT;
+    }
     return ACCBPG_OK;
 }

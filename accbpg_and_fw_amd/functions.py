@@ -338,6 +338,70 @@ class DOptimalObj(RSmoothFunction):
         return out
 
 
+class PoissonRegression(RSmoothFunction):
+    """f(x) = D_KL(b, Ax) for the linear inverse problem A x = b  (accbpg/functions.py:85-120).
+
+    ``A`` (m x n) and ``b`` may be NumPy arrays (copied to the GPU once) or fp64 CUDA tensors
+    (borrowed); ``self.A``, ``self.b``, ``self.m``, ``self.n`` stay readable as in the reference.
+    Each func_grad is two passes over A: A x with the KL terms fused into its epilogue, then A^T r."""
+
+    def __init__(self, A, b):
+        assert A.shape[0] == b.shape[0], "A and b sizes not matching"
+        self.A = A
+        self.b = b
+        self.m = A.shape[0]
+        self.n = A.shape[1]
+        self._A, _ = to_dev(A)
+        self._b, _ = to_dev(b)
+        lib = _lib.load()
+        h = C.c_void_p()
+        with torch.cuda.device(self._A.device):
+            rc = lib.accbpg_poisson_create(_ptr(self._A), self.m, self.n, self._A.stride(0), _ptr(self._b),
+                                           _stream(), C.byref(h))
+        _lib.check(rc, "accbpg_poisson_create")
+        self._h = h
+        self._lib = lib
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self._lib.accbpg_poisson_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def __call__(self, x):
+        return self.func_grad(x, flag=0)
+
+    def gradient(self, x):
+        return self.func_grad(x, flag=1)
+
+    def func_grad(self, x, flag=2):
+        size = x.numel() if isinstance(x, torch.Tensor) else x.size
+        assert size == self.n, "PoissonRegression: x.size not equal to n."
+        xd, was_np = to_dev(x)
+        g = torch.empty(self.n, dtype=torch.float64, device=self._A.device) if flag != 0 else None
+        fval = C.c_double(0.0)
+        with torch.cuda.device(self._A.device):
+            self._lib.accbpg_poisson_set_stream(self._h, _stream())
+            rc = self._lib.accbpg_poisson_func_grad(self._h, _ptr(xd), int(flag), C.byref(fval), _ptr(g))
+        _lib.check(rc, "accbpg_poisson_func_grad")
+        if flag == 0:
+            return fval.value
+        if flag == 1:
+            return from_dev(g, was_np)
+        return fval.value, from_dev(g, was_np)
+
+    def fitted(self):
+        """A x of the last evaluation (length m) as a NumPy vector."""
+        out = torch.empty(self.m, dtype=torch.float64, device=self._A.device)
+        with torch.cuda.device(self._A.device):
+            rc = self._lib.accbpg_poisson_get_ax(self._h, _ptr(out))
+        _lib.check(rc, "accbpg_poisson_get_ax")
+        return out.cpu().numpy()
+
+
 # ------------------------------------------------------------------ h
 class LegendreFunction:
     """Legendre kernel protocol (accbpg/functions.py:199-235)."""
@@ -389,19 +453,68 @@ class BurgEntropy(LegendreFunction):
         _lib.check(rc, "accbpg_burg_divergence", "Entries of x or y not positive.")
         return out.value
 
+    _kind = 0       # closed-form variant of accbpg_burg_reg_div_prox
+    lamda = 0
+
+    def _reg_prox(self, y, g, L):
+        gd, was_np = to_dev(g)
+        yd = None
+        if y is not None:
+            yd, _ = to_dev(y)
+        out = torch.empty_like(gd)
+        with torch.cuda.device(gd.device):
+            rc = _lib.load().accbpg_burg_reg_div_prox(self._kind, _ptr(yd), _ptr(gd), float(L), float(self.lamda),
+                                                      gd.numel(), _ptr(out), _stream())
+        _lib.check(rc, "accbpg_burg_reg_div_prox")
+        return from_dev(out, was_np)
+
     def prox_map(self, g, L):
         assert L > 0, "BurgEntropy prox_map only takes positive L value."
-        gd, was_np = to_dev(g)
-        assert float(gd.min()) > 0, "BurgEntropy prox_map only takes positive value."
-        return from_dev(L / gd, was_np)
+        return self._reg_prox(None, g, L)       # g.min() > 0 is checked on the device (functions.py:261)
 
     def div_prox_map(self, y, g, L):
         assert y.shape == g.shape, "Vectors y and g are of different sizes."
-        yd, was_np = to_dev(y)
-        assert float(yd.min()) > 0 and L > 0, "Either y or L is not positive."
-        gd, _ = to_dev(g)
-        res = self.prox_map(gd - L * (-1.0 / yd), L)
-        return from_dev(res, was_np)
+        assert L > 0, "Either y or L is not positive."
+        return self._reg_prox(y, g, L)          # y.min() > 0 is checked on the device (functions.py:270)
+
+
+class BurgEntropyL1(BurgEntropy):
+    """Burg entropy for min_{x>0} f(x) + lamda*||x||_1  (accbpg/functions.py:274-298)."""
+    _kind = 1
+
+    def __init__(self, lamda=0, x_max=1e4):
+        assert lamda >= 0, "BurgEntropyL1: lambda should be nonnegative."
+        self.lamda = lamda
+        self.x_max = x_max
+
+    def extra_Psi(self, x):
+        if self.lamda == 0:
+            return 0.0
+        xd, _ = to_dev(x)
+        return self.lamda * vec_min_sum(xd)[1]
+
+    def prox_map(self, g, L):
+        assert L > 0, "BurgEntropyL1: prox_map only takes positive L."
+        return self._reg_prox(None, g, L)       # g.min() > -lamda is checked on the device (:296)
+
+
+class BurgEntropyL2(BurgEntropy):
+    """Burg entropy for min_{x>0} f(x) + (lamda/2)*||x||_2^2  (accbpg/functions.py:301-323)."""
+    _kind = 2
+
+    def __init__(self, lamda=0):
+        assert lamda >= 0, "BurgEntropyL2: lamda should be nonnegative."
+        self.lamda = lamda
+
+    def extra_Psi(self, x):
+        if self.lamda == 0:
+            return 0.0
+        xd, _ = to_dev(x)
+        return (self.lamda / 2) * vec_dot(xd, xd)
+
+    def prox_map(self, g, L):
+        assert L > 0, "BurgEntropyL2: prox_map only takes positive L value."
+        return self._reg_prox(None, g, L)
 
 
 class BurgEntropySimplex(BurgEntropy):
@@ -455,6 +568,16 @@ def vec_dot_diff(g, x, y):
         ws = _Workspace.get(x.numel(), x.device)
         rc = _lib.load().accbpg_vec_dot_diff(_ptr(g), _ptr(x), _ptr(y), x.numel(), C.byref(out), _ptr(ws), _stream())
     _lib.check(rc, "accbpg_vec_dot_diff")
+    return out.value
+
+
+def vec_dot(x, y):
+    """<x, y>  (np.dot(x, x) of BurgEntropyL2.extra_Psi, functions.py:314)."""
+    out = C.c_double(0.0)
+    with torch.cuda.device(x.device):
+        ws = _Workspace.get(x.numel(), x.device)
+        rc = _lib.load().accbpg_vec_dot(_ptr(x), _ptr(y), x.numel(), C.byref(out), _ptr(ws), _stream())
+    _lib.check(rc, "accbpg_vec_dot")
     return out.value
 
 

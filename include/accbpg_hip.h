@@ -176,6 +176,37 @@ int accbpg_fw_update(accbpg_dopt* h, int64_t p, double xscale, double xadd, doub
 /* Copy state out (device to device): x (n), w (n), H (m*m, row-major).  NULL skips. */
 int accbpg_fw_get_state(accbpg_dopt* h, double* x_dev, double* w_dev, double* H_dev);
 
+/* ---- Poisson linear inverse problem with Burg L1 / L2 kernels -------- */
+
+typedef struct accbpg_poisson accbpg_poisson;
+
+/* f(x) = D_KL(b, Ax): replaces PoissonRegression.__init__ (accbpg/functions.py:89-94).  A is a row-major
+ * m x n device matrix with leading dimension lda, b a length-m device vector; both stay owned by the caller
+ * and must outlive the handle. */
+int accbpg_poisson_create(const double* A_dev, int64_t m, int64_t n, int64_t lda, const double* b_dev,
+                          void* stream, accbpg_poisson** out);
+int accbpg_poisson_destroy(accbpg_poisson* h);
+int accbpg_poisson_set_stream(accbpg_poisson* h, void* stream);
+
+/* PoissonRegression.func_grad (accbpg/functions.py:102-120): flag 0 -> *f_host = sum(b*log(b/Ax) + Ax - b);
+ * flag 1 -> g_dev = A^T (1 - b/Ax); flag 2 -> both.  Synchronises the stream when a value is returned. */
+int accbpg_poisson_func_grad(accbpg_poisson* h, const double* x_dev, int flag, double* f_host, double* g_dev);
+
+/* out_dev <- Ax of the last func_grad (length m). */
+int accbpg_poisson_get_ax(accbpg_poisson* h, double* out_dev);
+
+/* Closed-form Burg-entropy prox maps on x > 0.  kind 0: BurgEntropy.prox_map L/g (accbpg/functions.py:255-262);
+ * kind 1: BurgEntropyL1.prox_map L/(lamda+g) (:290-298); kind 2: BurgEntropyL2.prox_map (:316-323).  With
+ * y_dev != NULL the argument is g - L*(-1/y) first, i.e. BurgEntropy.div_prox_map (:264-271).
+ * ACCBPG_ERR_ASSERT where the reference asserts: L <= 0, y.min() <= 0, g.min() <= 0 (kind 0),
+ * g.min() <= -lamda (kind 1). */
+int accbpg_burg_reg_div_prox(int kind, const double* y_dev, const double* g_dev, double L, double lamda,
+                             int64_t n, double* x_out_dev, void* stream);
+
+/* *out_host = <x, y>  (np.dot(x, x) of BurgEntropyL2.extra_Psi, accbpg/functions.py:314). */
+int accbpg_vec_dot(const double* x_dev, const double* y_dev, int64_t n, double* out_host, double* ws_dev,
+                   void* stream);
+
 /* ---- diagnostics ---------------------------------------------------------------------- */
 
 /* Kernel time accounting for the roofline line of bench.py: accumulates HIP-event durations

@@ -220,6 +220,64 @@ def next_rows(accbpg):
     save("next_rows", **out)
 
 
+def poisson(accbpg):
+    """PoissonRegression + BurgEntropyL1/L2, with the calls of ipynb/ex_Poisson_L2.ipynb
+    (cells 1, 3 and 5) at a reduced iteration count.  A is not stored: the tests rebuild it with the same legacy
+    NumPy RNG call sequence the factory uses (accbpg/applications.py:114-121) and compare the checksum."""
+    import numpy as np
+    out = {}
+    N = 2000
+    for tag, fac, m, n, noise, lam in [("l1", accbpg.Poisson_regrL1, 200, 100, 0.0001, 0),
+                                       ("l2", accbpg.Poisson_regrL2, 100, 1000, 0.001, 0.001),
+                                       ("l1r", accbpg.Poisson_regrL1, 300, 2000, 0.001, 0.01)]:
+        f, h, L, x0 = fac(m, n, noise=noise, lamda=lam, randseed=1)
+        out[tag + "_cfg"] = np.array([m, n, noise, lam])
+        out[tag + "_A_checksum"] = np.array([f.A.sum(), np.abs(f.A).max(), (f.A ** 2).sum()])
+        out[tag + "_b"] = f.b
+        out[tag + "_L"] = L
+        out[tag + "_x0"] = x0
+        rng = np.random.RandomState(77)
+        x = rng.rand(n) * (2.0 / n) + 1e-3
+        y = rng.rand(n) * (2.0 / n) + 1e-3
+        fx, g = f.func_grad(x, 2)
+        out.update({tag + "_x": x, tag + "_y": y, tag + "_f": fx, tag + "_g": g, tag + "_f0": f(x0),
+                    tag + "_g0": f.gradient(x0), tag + "_psi": h.extra_Psi(x)})
+        for idx, Lc in enumerate([L, 0.37 * L, 5.0]):
+            out["%s_prox_L%d" % (tag, idx)] = Lc
+            out["%s_prox_x%d" % (tag, idx)] = h.div_prox_map(y, g, Lc)
+        out[tag + "_prox_raw"] = h.prox_map(np.abs(g) + 0.5, 2.0)
+        out[tag + "_div_xy"] = h.divergence(x, y)
+
+    f, h, L, x0 = accbpg.Poisson_regrL1(200, 100, noise=0.0001, lamda=0, randseed=1)
+    x, F, Ls, T = accbpg.BPG(f, h, L, x0, maxitrs=N, linesearch=False, verbose=False)
+    out.update(l1_bpg_x=x, l1_bpg_F=F)
+    x, F, Ls, T = accbpg.BPG(f, h, L, x0, maxitrs=N, linesearch=True, verbose=False)
+    out.update(l1_bpgls_x=x, l1_bpgls_F=F, l1_bpgls_Ls=Ls)
+    for gam, key in [(1.0, "g10"), (1.5, "g15"), (2.0, "g20")]:
+        x, F, G, T = accbpg.ABPG(f, h, L, x0, gamma=gam, maxitrs=N, theta_eq=True, verbose=False)
+        out.update({"l1_abpg_%s_x" % key: x, "l1_abpg_%s_F" % key: F, "l1_abpg_%s_G" % key: G})
+    x, F, G, T = accbpg.ABDA(f, h, L, x0, gamma=2.0, maxitrs=N, theta_eq=True, verbose=False)
+    out.update(l1_abda_x=x, l1_abda_F=F, l1_abda_G=G)
+    x, F, Gamma, G, T = accbpg.ABPG_expo(f, h, L, x0, gamma0=3, maxitrs=N, theta_eq=False, Gmargin=3, verbose=False)
+    out.update(l1_expo_x=x, l1_expo_F=F, l1_expo_Gamma=Gamma, l1_expo_G=G)
+    x, F, G, Gdiv, Gavg, T = accbpg.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=N, G0=0.1, theta_eq=False, verbose=False)
+    out.update(l1_gain_x=x, l1_gain_F=F, l1_gain_G=G, l1_gain_Gdiv=Gdiv, l1_gain_Gavg=Gavg)
+
+    f, h, L, x0 = accbpg.Poisson_regrL2(100, 1000, noise=0.001, lamda=0.001, randseed=1)
+    x, F, Ls, T = accbpg.BPG(f, h, L, x0, maxitrs=N, linesearch=False, verbose=False)
+    out.update(l2_bpg_x=x, l2_bpg_F=F)
+    x, F, Ls, T = accbpg.BPG(f, h, L, x0, maxitrs=N, linesearch=True, ls_ratio=1.5, verbose=False)
+    out.update(l2_bpgls_x=x, l2_bpgls_F=F, l2_bpgls_Ls=Ls)
+    x, F, G, T = accbpg.ABPG(f, h, L, x0, gamma=2.0, maxitrs=N, theta_eq=False, verbose=False)
+    out.update(l2_abpg_x=x, l2_abpg_F=F, l2_abpg_G=G)
+    x, F, Gamma, G, T = accbpg.ABPG_expo(f, h, L, x0, gamma0=3, maxitrs=N, theta_eq=False, Gmargin=1, verbose=False)
+    out.update(l2_expo_x=x, l2_expo_F=F, l2_expo_Gamma=Gamma, l2_expo_G=G)
+    x, F, G, Gdiv, Gavg, T = accbpg.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=N, G0=0.1, ls_inc=1.5, ls_dec=1.5,
+                                              theta_eq=True, verbose=False)
+    out.update(l2_gain_x=x, l2_gain_F=F, l2_gain_G=G, l2_gain_Gdiv=Gdiv, l2_gain_Gavg=Gavg)
+    save("poisson", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--medium", action="store_true")
@@ -227,12 +285,16 @@ def main():
     ap.add_argument("--only-large", action="store_true")
     ap.add_argument("--only-traces", action="store_true")
     ap.add_argument("--only-next", action="store_true")
+    ap.add_argument("--only-poisson", action="store_true")
     ap.add_argument("--out", default=None, help="write into this directory instead of tests/golden")
     args = ap.parse_args()
     accbpg = load_reference()
     if args.out:
         global OUT
         OUT = args.out
+    if args.only_poisson:
+        poisson(accbpg)
+        return
     if args.only_next:
         next_rows(accbpg)
         return
@@ -252,6 +314,7 @@ def main():
         fw_traces(accbpg, "64x512", 64, 512, 2, 3000)
         housing(accbpg)
         next_rows(accbpg)
+        poisson(accbpg)
     if args.medium:
         traces_512(accbpg)
         percall(accbpg, "512x8192", 512, 8192, 1)

@@ -595,3 +595,109 @@ def D_opt_libsvm(filename):
     H = np.ascontiguousarray(X.T) if X.shape[0] > X.shape[1] else np.ascontiguousarray(X)
     n = H.shape[1]
     return DOptOracle(H), BurgSimplexOracle(), 1.0, (1.0 / n) * np.ones(n)
+
+
+# --------------------------------------------------------------------------
+# Poisson linear inverse problem with Burg L1 / L2 kernels
+#                                          accbpg/functions.py:85-120, 274-323
+#                                          accbpg/applications.py:98-175
+# --------------------------------------------------------------------------
+class PoissonOracle:
+    """f(x) = D_KL(b, Ax) = sum_i b_i log(b_i/(Ax)_i) + (Ax)_i - b_i.
+
+    Follows functions.py:103-120: one matrix-vector product (:105), the value is
+    a left-to-right builtin ``sum`` (:107, :119), the gradient is the row sum over
+    axis 0 of (1 - b/Ax)[:, None] * A (:111), flag 0 returns before the gradient."""
+
+    def __init__(self, A, b):
+        assert A.shape[0] == b.shape[0], "A and b sizes not matching"
+        self.A, self.b = A, b
+        self.m, self.n = A.shape
+
+    def func_grad(self, x, flag=2):
+        assert x.size == self.n, "PoissonRegression: x.size not equal to n."
+        Ax = np.dot(self.A, x)
+        if flag == 0:
+            return _seq_sum(self.b * np.log(self.b / Ax) + Ax - self.b)
+        grad = ((1 - self.b / Ax).reshape(self.m, 1) * self.A).sum(axis=0)
+        if flag == 1:
+            return grad
+        return _seq_sum(self.b * np.log(self.b / Ax) + Ax - self.b), grad
+
+    def __call__(self, x):
+        return self.func_grad(x, flag=0)
+
+    def gradient(self, x):
+        return self.func_grad(x, flag=1)
+
+
+class BurgOracle(BurgSimplexOracle):
+    """Unconstrained Burg entropy (functions.py:238-271): prox_map is L/g for g > 0."""
+
+    def __init__(self):
+        pass
+
+    def prox_map(self, g, L):           # functions.py:255-262
+        assert L > 0, "BurgEntropy prox_map only takes positive L value."
+        assert g.min() > 0, "BurgEntropy prox_map only takes positive value."
+        return L / g
+
+
+class BurgL1Oracle(BurgOracle):
+    """Burg entropy with Psi(x) = lamda*||x||_1 on x > 0 (functions.py:274-298)."""
+
+    def __init__(self, lamda=0, x_max=1e4):
+        assert lamda >= 0, "BurgEntropyL1: lambda should be nonnegative."
+        self.lamda, self.x_max = lamda, x_max
+
+    def extra_Psi(self, x):             # :284-288
+        return self.lamda * x.sum()
+
+    def prox_map(self, g, L):           # :290-298
+        assert L > 0, "BurgEntropyL1: prox_map only takes positive L."
+        assert g.min() > -self.lamda, "Not getting positive solution."
+        return L / (self.lamda + g)
+
+
+class BurgL2Oracle(BurgOracle):
+    """Burg entropy with Psi(x) = (lamda/2)*||x||_2^2 (functions.py:301-323)."""
+
+    def __init__(self, lamda=0):
+        assert lamda >= 0, "BurgEntropyL2: lamda should be nonnegative."
+        self.lamda = lamda
+
+    def extra_Psi(self, x):             # :310-314
+        return (self.lamda / 2) * np.dot(x, x)
+
+    def prox_map(self, g, L):           # :316-323 (positive root of lamda_L*t^2 + gg*t - 1)
+        assert L > 0, "BurgEntropyL2: prox_map only takes positive L value."
+        gg = g / L
+        lamda_L = self.lamda / L
+        return (np.sqrt(gg * gg + 4 * lamda_L) - gg) / (2 * lamda_L)
+
+
+def poisson_instance(m, n, noise=0.01, randseed=-1, normalizeA=True):
+    """(A, b) of Poisson_regrL1/L2 (applications.py:114-123 == :153-162): uniform A with unit column
+    sums, a sparse nonnegative x, b = A x + centred uniform noise; the legacy global RNG is drawn in the
+    order A, x, noise."""
+    if randseed > 0:
+        np.random.seed(randseed)
+    A = np.random.rand(m, n)
+    if normalizeA:
+        A = A / A.sum(axis=0)
+    x = np.random.rand(n) / n
+    xavg = x.sum() / x.size
+    x = np.maximum(x - xavg, 0) * 10
+    b = np.dot(A, x) + noise * (np.random.rand(m) - 0.5)
+    assert b.min() > 0, "need b > 0 for nonnegative regression."
+    return A, b
+
+
+def Poisson_regrL1(m, n, noise=0.01, lamda=0, randseed=-1, normalizeA=True):
+    A, b = poisson_instance(m, n, noise, randseed, normalizeA)
+    return PoissonOracle(A, b), BurgL1Oracle(lamda), b.sum(), (1.0 / n) * np.ones(n) * 10   # :125-131
+
+
+def Poisson_regrL2(m, n, noise=0.01, lamda=0, randseed=-1, normalizeA=True):
+    A, b = poisson_instance(m, n, noise, randseed, normalizeA)
+    return PoissonOracle(A, b), BurgL2Oracle(lamda), b.sum(), (1.0 / n) * np.ones(n)        # :164-170

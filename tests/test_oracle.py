@@ -201,3 +201,91 @@ def test_kyinit_matches_reference():
     assert np.count_nonzero(xky) <= 60 and abs(xky.sum() - 1) < 1e-14
     # n <= 2m falls back to the uniform point (applications.py:67-68)
     np.testing.assert_array_equal(O.D_opt_KYinit(np.zeros((30, 60))), np.ones(60) / 60)
+
+
+# ---------------------------------------------------------------- Poisson + Burg L1/L2
+_POISSON = {"l1": (O.Poisson_regrL1, 200, 100, 0.0001, 0), "l2": (O.Poisson_regrL2, 100, 1000, 0.001, 0.001),
+            "l1r": (O.Poisson_regrL1, 300, 2000, 0.001, 0.01)}
+
+
+def _poisson_instance(tag):
+    """Factory instance with b and L pinned to the golden run (b = A x + noise goes through the host BLAS,
+    which may differ by an ulp between machines)."""
+    fac, m, n, noise, lam = _POISSON[tag]
+    f, h, L, x0 = fac(m, n, noise=noise, lamda=lam, randseed=1)
+    gd = golden("poisson")
+    np.testing.assert_allclose(f.b, gd[tag + "_b"], rtol=1e-13)
+    assert L == pytest.approx(float(gd[tag + "_L"]), rel=1e-13)
+    return O.PoissonOracle(f.A, gd[tag + "_b"]), h, float(gd[tag + "_L"]), x0
+
+
+@pytest.mark.parametrize("tag", ["l1", "l2", "l1r"])
+def test_poisson_percall_matches_reference(tag):
+    gd = golden("poisson")
+    f, h, L, x0 = _poisson_instance(tag)
+    A = f.A
+    np.testing.assert_allclose([A.sum(), np.abs(A).max(), (A ** 2).sum()], gd[tag + "_A_checksum"], rtol=1e-14)
+    np.testing.assert_array_equal(x0, gd[tag + "_x0"])
+    x, y = gd[tag + "_x"], gd[tag + "_y"]
+    fx, g = f.func_grad(x, 2)
+    assert fx == pytest.approx(float(gd[tag + "_f"]), rel=1e-12, abs=1e-13)
+    np.testing.assert_allclose(g, gd[tag + "_g"], rtol=1e-11, atol=1e-13)
+    assert f(x0) == pytest.approx(float(gd[tag + "_f0"]), rel=1e-12, abs=1e-13)
+    np.testing.assert_allclose(f.gradient(x0), gd[tag + "_g0"], rtol=1e-11, atol=1e-13)
+    assert h.extra_Psi(x) == pytest.approx(float(gd[tag + "_psi"]), rel=1e-15)
+    for idx in range(3):
+        z = h.div_prox_map(y, gd[tag + "_g"], float(gd["%s_prox_L%d" % (tag, idx)]))
+        np.testing.assert_array_equal(z, gd["%s_prox_x%d" % (tag, idx)])      # elementwise -> bitwise
+    np.testing.assert_array_equal(h.prox_map(np.abs(gd[tag + "_g"]) + 0.5, 2.0), gd[tag + "_prox_raw"])
+    assert h.divergence(x, y) == float(gd[tag + "_div_xy"])
+
+
+def test_poisson_l1_solver_traces_match_reference():
+    gd = golden("poisson")
+    f, h, L, x0 = _poisson_instance("l1")
+    N, tol = 2000, 1e-10
+    x, F, Ls, T = O.BPG(f, h, L, x0, maxitrs=N, linesearch=False)
+    _check(x, gd["l1_bpg_x"], tol); _check(F, gd["l1_bpg_F"], tol)
+    for gam, key in [(1.0, "g10"), (1.5, "g15"), (2.0, "g20")]:
+        x, F, G, T = O.ABPG(f, h, L, x0, gamma=gam, maxitrs=N, theta_eq=True)
+        _check(x, gd["l1_abpg_%s_x" % key], 1e-8); _check(F, gd["l1_abpg_%s_F" % key], tol)
+    x, F, G, T = O.ABDA(f, h, L, x0, gamma=2.0, maxitrs=N, theta_eq=True)
+    _check(x, gd["l1_abda_x"], 1e-8); _check(F, gd["l1_abda_F"], tol)
+    # line-search runs: decision-stable prefix, then objective-level agreement (see the note above)
+    x, F, Ls, T = O.BPG(f, h, L, x0, maxitrs=N, linesearch=True)
+    p = _prefix(Ls, gd["l1_bpgls_Ls"], 1e-12)
+    assert p >= 100, p
+    _check(F[:p], gd["l1_bpgls_F"][:p], tol)
+    assert abs(F[-1] - gd["l1_bpgls_F"][-1]) < 1e-6
+    x, F, Gamma, G, T = O.ABPG_expo(f, h, L, x0, gamma0=3, maxitrs=N, theta_eq=False, Gmargin=3)
+    p = _prefix(Gamma, gd["l1_expo_Gamma"], 1e-12)
+    assert p >= 100, p
+    _check(F[:p], gd["l1_expo_F"][:p], tol)
+    x, F, G, Gdiv, Gavg, T = O.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=N, G0=0.1, theta_eq=False)
+    p = _prefix(G, gd["l1_gain_G"], 1e-12)
+    assert p >= 100, p
+    _check(F[:p], gd["l1_gain_F"][:p], tol)
+    assert abs(F[-1] - gd["l1_gain_F"][-1]) < 1e-6
+
+
+def test_poisson_l2_solver_traces_match_reference():
+    gd = golden("poisson")
+    f, h, L, x0 = _poisson_instance("l2")
+    N, tol = 2000, 1e-10
+    x, F, Ls, T = O.BPG(f, h, L, x0, maxitrs=N, linesearch=False)
+    _check(x, gd["l2_bpg_x"], tol); _check(F, gd["l2_bpg_F"], tol)
+    x, F, G, T = O.ABPG(f, h, L, x0, gamma=2.0, maxitrs=N, theta_eq=False)
+    _check(x, gd["l2_abpg_x"], 1e-8); _check(F, gd["l2_abpg_F"], tol)
+    x, F, Ls, T = O.BPG(f, h, L, x0, maxitrs=N, linesearch=True, ls_ratio=1.5)
+    p = _prefix(Ls, gd["l2_bpgls_Ls"], 1e-12)
+    assert p >= 100, p
+    _check(F[:p], gd["l2_bpgls_F"][:p], tol)
+    x, F, Gamma, G, T = O.ABPG_expo(f, h, L, x0, gamma0=3, maxitrs=N, theta_eq=False, Gmargin=1)
+    p = _prefix(Gamma, gd["l2_expo_Gamma"], 1e-12)
+    assert p >= 100, p
+    _check(F[:p], gd["l2_expo_F"][:p], tol)
+    x, F, G, Gdiv, Gavg, T = O.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=N, G0=0.1, ls_inc=1.5, ls_dec=1.5,
+                                         theta_eq=True)
+    p = _prefix(G, gd["l2_gain_G"], 1e-12)
+    assert p >= 100, p
+    _check(F[:p], gd["l2_gain_F"][:p], tol)
