@@ -149,12 +149,15 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");   // stage 0 landed (this wave's share)
             __builtin_amdgcn_s_barrier();
             int cur = 0;
+            // The barrier sits BEFORE the last fragment group's MFMAs: the first fragments of the next
+            // stage are read right behind it and land while those 32 MFMAs occupy the matrix pipe, so
+            // the pipe has work queued across the barrier instead of waiting out an LDS round trip.
+            t.template read_frag_g<0, true>(lds, 0);
 #pragma unroll 1
             for (int64_t ks = kb; ks < ke; ++ks) {
                 int nx2 = cur + 2;
                 if (nx2 >= 3) nx2 -= 3;
                 const double* st = lds + cur * T::G_STAGE;
-                t.template read_frag_g<0, true>(st, 0);
                 t.template read_frag_g<1, true>(st, 1);
                 t.template mma_frag<0>();
                 if constexpr (!(GV & 1)) issue(min(ks + 2, klast), nx2);   // that buffer was last read in step ks-1
@@ -162,13 +165,16 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
                 t.template mma_frag<1>();
                 t.template read_frag_g<1, true>(st, 3);
                 t.template mma_frag<0>();
-                t.template mma_frag<1>();
-                // stage ks+1 (issued one step ago) must have landed: all but the newest NLD loads done
+                // stage ks+1 (issued one step ago) must have landed: all but the newest NLD loads done;
+                // lgkmcnt(0): this wave's reads of stage ks are complete before others may overwrite it
                 if constexpr (!(GV & 2)) {
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLD) : "memory");
                     __builtin_amdgcn_s_barrier();
                 }
                 cur = (cur + 1 == 3) ? 0 : cur + 1;
+                // (after the last step this reads the redundant, already landed copy of stage klast)
+                t.template read_frag_g<0, true>(lds + cur * T::G_STAGE, 0);
+                t.template mma_frag<1>();
             }
         } else {
             issue(kb, 0);
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
                 cur ^= 1;
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // redundant tail loads retire before LDS is reused
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // tail loads / reads retire before LDS is reused
         if (kb == 0 && ke == kiters) {
             t.store_C(G, ldg, row0, col0, m, m, 1.0, 0.0, true);
         } else {
@@ -357,6 +363,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void colnorm_glds_kernel(
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
         __builtin_amdgcn_s_barrier();
         int cur = 0;
+        t.template read_frag_g<0, false>(lds, 0);
 #pragma unroll 1
         for (int64_t ks = 0; ks < ksteps; ++ks) {
             int nx2 = cur + 2;
@@ -368,7 +375,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void colnorm_glds_kernel(
                 const int64_t num = kd - 15 - 16 * wm;
                 mi_lo = num > 0 ? (int)((num + 16 * T::WAVES_M - 1) / (16 * T::WAVES_M)) : 0;
             }
-            t.template read_frag_g<0, false>(st, 0);
             t.template read_frag_g<1, false>(st, 1);
             t.template mma_frag<0>(mi_lo);
             issue(min(ks + 2, klast), nx2);
@@ -376,12 +382,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void colnorm_glds_kernel(
             t.template mma_frag<1>(mi_lo);
             t.template read_frag_g<1, false>(st, 3);
             t.template mma_frag<0>(mi_lo);
-            t.template mma_frag<1>(mi_lo);
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLD) : "memory");
             __builtin_amdgcn_s_barrier();
             cur = (cur + 1 == 3) ? 0 : cur + 1;
+            // first fragments of the next stage land under the last group's MFMAs (see the Gram kernel)
+            t.template read_frag_g<0, false>(lds + cur * T::G_STAGE, 0);
+            t.template mma_frag<1>(mi_lo);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int j = 0; j < T::NI; ++j) {
             double s = 0.0;

@@ -6,7 +6,7 @@ every rank owns an independent instance of the same shape (seeds 1..N) -- instan
 no data-path collective ("scaling": "weak"); the whole-job value is N ranks' iterations over
 the max-over-ranks time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload abpg_gain|abpg|bpg|fw|fw_away]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload abpg_gain|abpg|bpg|fw|fw_away|poisson_abpg|poisson_bpg]
                     [--m 2048 --n 32768] [--no-cpu-baseline]
 
 Prints ONE JSON line on rank 0 (contract in the task description), including
@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="abpg_gain", choices=["abpg_gain", "abpg", "bpg", "fw", "fw_away"])
+    ap.add_argument("--workload", default="abpg_gain", choices=["abpg_gain", "abpg", "bpg", "fw", "fw_away", "poisson_abpg", "poisson_bpg"])
     ap.add_argument("--m", type=int, default=2048)
     ap.add_argument("--n", type=int, default=32768)
     ap.add_argument("--mode", default="instances", choices=["instances", "shard"],
@@ -84,8 +84,89 @@ class FWStepper:
             st.update(pr.j, 1 + t, -t, coef, 1 + t)
 
 
+# ---- Poisson linear inverse problem (HBM-bound objective), single GPU
+def poisson_instance(acc, torch, m, n, seed, lamda):
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    A = torch.rand(m, n, dtype=torch.float64, device="cuda", generator=gen)
+    A /= A.sum(0, keepdim=True)
+    x = torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) / n
+    x = torch.clamp(x - x.mean(), min=0) * 10
+    b = A @ x + 0.001 * (torch.rand(m, dtype=torch.float64, device="cuda", generator=gen) - 0.5) / m
+    b = torch.clamp(b, min=1e-12)
+    f = acc.PoissonRegression(A, b)
+    return f, acc.BurgEntropyL2(lamda), float(b.sum()), torch.full((n,), 1.0 / n, dtype=torch.float64, device="cuda")
+
+
+def poisson_main(args):
+    import torch
+    import accbpg_and_fw_amd as acc
+    from accbpg_and_fw_amd.algorithms import ABPG_steps, BPG_steps
+    m, n = (args.m, args.n) if (args.m, args.n) != (2048, 32768) else (8192, 65536)
+    solver = args.workload.split('_')[1]
+    f, h, L, x0 = poisson_instance(acc, torch, m, n, 1, 0.001)
+    total = args.steps + args.warmup
+    if solver == "abpg":
+        gen = ABPG_steps(f, h, L, x0, gamma=2.0, maxitrs=total + 1, theta_eq=False, verbose=False)
+    else:
+        gen = BPG_steps(f, h, L, x0, maxitrs=total + 1, linesearch=True, ls_ratio=1.5, verbose=False)
+    for _ in range(args.warmup):
+        next(gen)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        next(gen)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    # the two passes, timed with events on the launch stream
+    x = x0.clone()
+    reps = 20
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    f.func_grad(x, 0); f.func_grad(x, 2)
+    ev[0].record()
+    for _ in range(reps):
+        f.func_grad(x, 0)
+    ev[1].record()
+    ev[2].record()
+    for _ in range(reps):
+        f.func_grad(x, 2)
+    ev[3].record()
+    torch.cuda.synchronize()
+    ms_val = ev[0].elapsed_time(ev[1]) / reps
+    ms_fg = ev[2].elapsed_time(ev[3]) / reps
+    byt = 8.0 * m * n
+    out = {
+        "metric": "Poisson iters/sec (m=%d,n=%d)" % (m, n), "value": args.steps / dt, "unit": "iterations/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "Poisson_regrL2-shaped instance (%d,%d) lamda=1e-3, %s, fp64" % (m, n, solver)},
+        "roofline": {"bound": "hbm", "kernel": "poisson_ax_kernel + fw_vgemv_partial_kernel (A x, then A^T r)",
+                     "achieved": 2 * byt / (ms_fg * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": 2 * byt / (ms_fg * 1e-3) / (PEAK_HBM_GBS * 1e9), "traffic": None,
+                     "avg_func_grad_ms": ms_fg, "value_only_ms": ms_val,
+                     "value_only_GBps": byt / (ms_val * 1e-3) / 1e9,
+                     "note": "includes the value readback (one stream sync) per call"},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import np_oracle as O
+        Ah, bh = f._A.cpu().numpy(), f._b.cpu().numpy()
+        fo, ho = O.PoissonOracle(Ah, bh), O.BurgL2Oracle(0.001)
+        it = 3
+        t0 = time.perf_counter()
+        if solver == "abpg":
+            O.ABPG(fo, ho, L, x0.cpu().numpy(), gamma=2.0, maxitrs=it, theta_eq=False)
+        else:
+            O.BPG(fo, ho, L, x0.cpu().numpy(), maxitrs=it, linesearch=True, ls_ratio=1.5)
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": it / cdt, "unit": "iterations/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": "%d oracle iterations of the same instance (NumPy, threaded BLAS)" % it}
+    print(json.dumps(out))
+
+
 def main():
     args = parse()
+    if args.workload.startswith("poisson"):      # SURVEY 8(f) row 4, single GPU, reported apart from the headline
+        return poisson_main(args)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -19,6 +19,7 @@ run fw "--workload fw --steps 200 --warmup 10 --cpu-iters 5"
 run fw_away "--workload fw_away --steps 40 --warmup 5 --cpu-iters 3"
 run cfg4 "--m 512 --n 8192 --workload abpg --steps 100 --warmup 10 --no-cpu-baseline"
 run cfg1 "--m 80 --n 200 --workload bpg --steps 500 --warmup 20 --no-cpu-baseline"
+run poisson "--workload poisson_abpg --steps 50 --warmup 5"
 run cfg4x8 "--m 512 --n 8192 --workload abpg --steps 100 --warmup 10 --no-cpu-baseline --instances-per-gpu 8"
 export TMPDIR=/tmp; cd /tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_main -- python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $REPO/gpurun_out/prof_main.log 2>&1
