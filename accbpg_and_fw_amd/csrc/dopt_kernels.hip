@@ -14,6 +14,39 @@
 
 namespace accbpg {
 
+// One stream-K segment: the part of a tile a workgroup covers with the units [it, it1) it still owns.
+// The unit space has `kiters` units per ENTRY of the tile list and one k-step per unit.  An entry is a
+// BM x BN tile, or a pair of 128 x 128 diagonal blocks run as dual tiles (mfma_tile.hpp): a dual tile
+// covers K in kiters/2 steps of full MFMA work, so two of them fill one entry and equal unit ranges
+// stay equal work.
+struct GramSeg {
+    int64_t row0, col0, kb, ke;
+    bool dual, whole;
+};
+template <class T>
+__device__ __forceinline__ GramSeg gram_segment(const TileRC* __restrict__ tiles, int64_t kiters, int64_t it,
+                                                int64_t it1) {
+    const int e = (int)(it / kiters);
+    const int64_t off = it - (int64_t)e * kiters;
+    const TileRC tr = tiles[e];
+    GramSeg g;
+    if (tr.d1 < 0) {
+        g.row0 = (int64_t)tr.rb * T::BM; g.col0 = (int64_t)tr.cb * T::BN;
+        g.kb = off; g.ke = min(kiters, off + (it1 - it));
+        g.dual = false;
+        g.whole = (g.kb == 0 && g.ke == kiters);
+    } else {
+        const int64_t half = kiters >> 1;
+        const bool second = off >= half;
+        g.kb = second ? off - half : off;
+        g.ke = min(half, g.kb + (it1 - it));
+        g.row0 = g.col0 = (int64_t)(second ? tr.d2 : tr.d1) * (T::BM / 2);
+        g.dual = true;
+        g.whole = (g.kb == 0 && g.ke == half);
+    }
+    return g;
+}
+
 // =========================================================================================
 // Weighted Gram matrix  G = (V diag(x)) V^T, lower tiles only, stream-K.
 // The flattened (tile, k-step) space is cut into equal contiguous ranges, one per workgroup;
@@ -25,7 +58,8 @@ namespace accbpg {
 template <class T, int VAR = 0>
 __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_kernel(
     const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n, const double* __restrict__ x,
-    const TileRC* __restrict__ tiles, int ntiles, int64_t kiters, int64_t per, double* __restrict__ slabs,
+    const TileRC* __restrict__ tiles, int ntiles, int64_t kiters, int64_t per, int nslot,
+    double* __restrict__ slabs,
     double* __restrict__ G, int64_t ldg, bool vec_ok) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int64_t total = (int64_t)ntiles * kiters;
@@ -35,11 +69,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_kernel(
     int64_t it = it0;
     int seg = 0;
     while (it < it1) {
-        const int tile = (int)(it / kiters);
-        const int64_t kb = it - (int64_t)tile * kiters;
-        const int64_t ke = min(kiters, kb + (it1 - it));
-        const int64_t row0 = (int64_t)tiles[tile].rb * T::BM;
-        const int64_t col0 = (int64_t)tiles[tile].cb * T::BN;
+        const GramSeg sg = gram_segment<T>(tiles, kiters, it, it1);   // never dual: pairs exist on the glds path only
+        const int64_t kb = sg.kb, ke = sg.ke, row0 = sg.row0, col0 = sg.col0;
         t.zero();
         // prologue: stage k-step kb into buffer 0, start the loads of k-step kb+1
         t.gload_A(V, ldv, row0, m, kb * BK, n, vec_ok);
@@ -97,10 +128,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_kernel(
                 sched_post_barrier<32, T::A_PASS + T::B_PASS, T::MI + T::NI>();
             cur ^= 1;
         }
-        if (kb == 0 && ke == kiters) {
+        if (sg.whole) {
             t.store_C(G, ldg, row0, col0, m, m, 1.0, 0.0, true);
         } else {
-            t.store_slab(slabs + ((int64_t)blockIdx.x * 2 + (seg == 0 ? 0 : 1)) * T::SLAB_DOUBLES);
+            t.store_slab(slabs + ((int64_t)blockIdx.x * nslot + seg) * T::SLAB_DOUBLES);
         }
         it += ke - kb;
         ++seg;
@@ -117,7 +148,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_kernel(
 template <class T, int GV = 0, int NSTAGE = 3, int WPS = 1>
 __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
     const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n, const double* __restrict__ x,
-    const TileRC* __restrict__ tiles, int ntiles, int64_t kiters, int64_t per, double* __restrict__ slabs,
+    const TileRC* __restrict__ tiles, int ntiles, int64_t kiters, int64_t per, int nslot,
+    double* __restrict__ slabs,
     double* __restrict__ G, int64_t ldg) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NLD = T::G_NA + T::G_NB + 1;                  // loads per wave per stage
@@ -128,13 +160,49 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
     int64_t it = it0;
     int seg = 0;
     while (it < it1) {
-        const int tile = (int)(it / kiters);
-        const int64_t kb = it - (int64_t)tile * kiters;
-        const int64_t ke = min(kiters, kb + (it1 - it));
+        const GramSeg sg = gram_segment<T>(tiles, kiters, it, it1);
+        const int64_t kb = sg.kb, ke = sg.ke, row0 = sg.row0, col0 = sg.col0;
         const int64_t klast = ke - 1;
-        const int64_t row0 = (int64_t)tiles[tile].rb * T::BM;
-        const int64_t col0 = (int64_t)tiles[tile].cb * T::BN;
         t.zero();
+        if constexpr (NSTAGE == 3 && T::WAVES_N == 1) {
+            if (sg.dual) {
+                // dual diagonal tile: A image = the band at k-step ks and at ks + K/2, no B image
+                constexpr int NLDD = T::G_NLD_DUAL;
+                const int64_t khalf = (kiters >> 1) * BK;
+                t.glds_setup_A_dual(V, ldv, row0, khalf);
+                __builtin_amdgcn_s_barrier();
+                t.glds_issue_dual(kb * BK, x, khalf, lds);
+                t.glds_issue_dual(min(kb + 1, klast) * BK, x, khalf, lds + T::G_STAGE);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLDD) : "memory");
+                __builtin_amdgcn_s_barrier();
+                int cur = 0;
+                t.template read_frag_dual<0>(lds, 0);
+#pragma unroll 1
+                for (int64_t ks = kb; ks < ke; ++ks) {
+                    int nx2 = cur + 2;
+                    if (nx2 >= 3) nx2 -= 3;
+                    const double* st = lds + cur * T::G_STAGE;
+                    t.template read_frag_dual<1>(st, 1);
+                    t.template mma_dual<0>();
+                    t.glds_issue_dual(min(ks + 2, klast) * BK, x, khalf, lds + nx2 * T::G_STAGE);
+                    t.template read_frag_dual<0>(st, 2);
+                    t.template mma_dual<1>();
+                    t.template read_frag_dual<1>(st, 3);
+                    t.template mma_dual<0>();
+                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLDD) : "memory");
+                    __builtin_amdgcn_s_barrier();
+                    cur = (cur + 1 == 3) ? 0 : cur + 1;
+                    t.template read_frag_dual<0>(lds + cur * T::G_STAGE, 0);
+                    t.template mma_dual<1>();
+                }
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                // always through a slab: the fix-up adds the two K halves (fragment rows i and i + MI/2)
+                t.store_slab(slabs + ((int64_t)blockIdx.x * nslot + seg) * T::SLAB_DOUBLES);
+                it += ke - kb;
+                ++seg;
+                continue;
+            }
+        }
         t.glds_setup_A(V, ldv, row0);
         t.glds_setup_B_kc(V, ldv, col0);
         auto issue = [&](int64_t ks, int buf) {
@@ -201,36 +269,90 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
             }
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // tail loads / reads retire before LDS is reused
-        if (kb == 0 && ke == kiters) {
+        if (sg.whole) {
             t.store_C(G, ldg, row0, col0, m, m, 1.0, 0.0, true);
         } else {
-            t.store_slab(slabs + ((int64_t)blockIdx.x * 2 + (seg == 0 ? 0 : 1)) * T::SLAB_DOUBLES);
+            t.store_slab(slabs + ((int64_t)blockIdx.x * nslot + seg) * T::SLAB_DOUBLES);
         }
         it += ke - kb;
         ++seg;
     }
 }
 
-// grid = ntiles * T::MI: workgroup (tile, part) sums fragment row `part` of the tile's slabs, so
-// the reduction reads the slabs with MI times the workgroups (HBM-bound pass, not 72 CUs' worth)
+// grid = ntiles * 2 * T::MI * FIX_PJ: workgroup (entry, half, part, jq) sums column-fragment group jq of
+// fragment row `part` of the slabs of one tile (entry = a tile, or half 0/1 of a pair of dual diagonal
+// tiles): many small workgroups, because the pass is bound by HBM latency, not by 72 CUs' worth of adds
+constexpr int FIX_PJ = 4;
 template <class T>
 __global__ __launch_bounds__(NTHREADS, 2) void gram_fixup_kernel(
-    const TileRC* __restrict__ tiles, int ntiles, int64_t kiters, int64_t per, const double* __restrict__ slabs,
-    double* __restrict__ G, int64_t ldg, int64_t m) {
-    const int tile = blockIdx.x / T::MI, part = blockIdx.x % T::MI;
-    const int64_t first_it = (int64_t)tile * kiters, last_it = first_it + kiters - 1;
-    const int64_t w0 = first_it / per, w1 = last_it / per;
-    // both ends of the tile inside one workgroup's range: that workgroup ran it as one whole
-    // segment (kb == 0, ke == kiters) and stored it directly
-    if (w0 == w1) return;
-    T t;
-    t.zero();
+    const TileRC* __restrict__ tiles, int ntiles, int64_t kiters, int64_t per, int nslot,
+    const double* __restrict__ slabs, double* __restrict__ G, int64_t ldg, int64_t m) {
+    constexpr int JW = (T::NI + FIX_PJ - 1) / FIX_PJ;
+    const int jq = blockIdx.x % FIX_PJ;
+    const int b = blockIdx.x / FIX_PJ;
+    const int e = b / (2 * T::MI), hs = (b / T::MI) & 1, part = b % T::MI;
+    const int j0 = jq * JW, j1 = min(T::NI, j0 + JW);
+    if (j0 >= T::NI) return;
+    const TileRC tr = tiles[e];
+    const bool dual = tr.d1 >= 0;
+    if (!dual && hs == 1) return;
+    if (dual && part >= T::MI / 2) return;                  // rows i + MI/2 hold the second K half of rows i
+    const int64_t ulen = dual ? (kiters >> 1) : kiters;
+    const int64_t u0 = (int64_t)e * kiters + (hs ? ulen : 0), u1 = u0 + ulen - 1;
+    const int64_t w0 = u0 / per, w1 = u1 / per;
+    // both ends of an ordinary tile inside one workgroup's range: that workgroup ran it as one whole
+    // segment and stored it directly (dual tiles always leave slabs)
+    if (w0 == w1 && !dual) return;
+    int64_t row0 = (int64_t)tr.rb * T::BM, col0 = (int64_t)tr.cb * T::BN;
+    if (dual) row0 = col0 = (int64_t)(hs ? tr.d2 : tr.d1) * (T::BM / 2);
+    // column fragments entirely above the diagonal are never stored
+    if (col0 + 16 * j0 > row0 + 16 * (part * T::WAVES_M + T::WAVES_M - 1) + 15) return;
+    // (no Tile object here: a handful of accumulators per thread instead of the 256-register tile)
+    double a[JW][4];
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[jj][r] = 0.0;
+    const int tid = threadIdx.x;
+    const int64_t total = (int64_t)ntiles * kiters;
     for (int64_t w = w0; w <= w1; ++w) {
-        const int64_t wfirst_tile = (w * per) / kiters;
-        const int slot = (wfirst_tile == tile) ? 0 : 1;
-        t.add_slab_part(slabs + (w * 2 + slot) * T::SLAB_DOUBLES, part);
+        // slot = ordinal of this tile among the segments of workgroup w (replay of its walk)
+        int64_t it = w * per;
+        const int64_t it1 = min(it + per, total);
+        int slot = 0;
+        while (it < u0) {
+            const GramSeg sg = gram_segment<T>(tiles, kiters, it, it1);
+            it += sg.ke - sg.kb;
+            ++slot;
+        }
+        const double* sl = slabs + (w * nslot + slot) * T::SLAB_DOUBLES;
+#pragma unroll
+        for (int jj = 0; jj < JW; ++jj) {
+            const int j = j0 + jj;
+            if (j < j1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    a[jj][r] += sl[((part * T::NI + j) * 4 + r) * NTHREADS + tid];
+                    if (dual) a[jj][r] += sl[(((part + T::MI / 2) * T::NI + j) * 4 + r) * NTHREADS + tid];
+                }
+            }
+        }
     }
-    t.store_C_part(G, ldg, (int64_t)tiles[tile].rb * T::BM, (int64_t)tiles[tile].cb * T::BN, m, m, true, part);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / T::WAVES_N, wn = wave % T::WAVES_N;
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int jj = 0; jj < JW; ++jj) {
+        const int j = j0 + jj;
+        if (j < j1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + 16 * (part * T::WAVES_M + wm) + lq + 4 * r;
+                const int64_t col = col0 + wn * T::WN + 16 * j + lr;
+                if (row < m && col < m && col <= row) G[row * ldg + col] = a[jj][r];
+            }
+        }
+    }
 }
 
 // =========================================================================================
@@ -984,11 +1106,23 @@ int build_plans(accbpg_dopt* h) {
     const int BN = h->gram_mid ? 128 : (h->big ? TileBig<false>::BN : TileSmall<false>::BN);
     std::vector<TileRC> tl;
     const int nrb = (int)((m + BM - 1) / BM), ncb = (int)((m + BN - 1) / BN);
+    h->kiters = (h->n + BK - 1) / BK;
+    // 256x128 tiles: the tile (rb, 2rb+1) next to the diagonal holds one useful 128 x 128 block, the odd
+    // diagonal block 2rb+1, under 128 rows that lie strictly above the diagonal.  On the direct-to-LDS
+    // path those blocks run as dual tiles instead (half of K each at full MFMA work), two per entry.
+    const bool duals = h->big && !h->gram_mid && interior256 && h->use_glds && (h->kiters % 2 == 0) && BM == 2 * BN;
+    std::vector<int> lone;
     for (int rb = 0; rb < nrb; ++rb)
         for (int cb = 0; cb < ncb; ++cb)
-            if ((int64_t)cb * BN <= (int64_t)rb * BM + BM - 1) tl.push_back(TileRC{rb, cb});
+            if ((int64_t)cb * BN <= (int64_t)rb * BM + BM - 1) {
+                if (duals && cb == 2 * rb + 1) lone.push_back(cb);
+                else tl.push_back(TileRC{rb, cb});
+            }
+    for (size_t i = 0; i + 1 < lone.size(); i += 2)
+        tl.push_back(TileRC{lone[i] / 2, lone[i], lone[i], lone[i + 1]});
+    if (lone.size() & 1) tl.push_back(TileRC{lone.back() / 2, lone.back()});   // odd one out: ordinary tile
+    h->has_duals = lone.size() >= 2;
     h->ntiles = (int)tl.size();
-    h->kiters = (h->n + BK - 1) / BK;
     const int64_t total = (int64_t)h->ntiles * h->kiters;
     int grid = (h->big && !h->gram_mid) ? h->num_cu : 2 * h->num_cu;
     if (grid > total) grid = (int)total;
@@ -1019,10 +1153,11 @@ int build_plans(accbpg_dopt* h) {
                     if (!used[i] && tl[i].rb == rb && tl[i].cb == cb) return (int)i;
                 return -1;
             };
+            const int bcols = (gs >= 2 && gs % 2 == 0) ? gs / 2 : 4;      // 2 x (gs/2) blocks fill one group
             for (int rp = nrb - 2 + (nrb & 1); rp >= -1; rp -= 2)
-                for (int c4 = 0; c4 < ncb; c4 += 4)
+                for (int c4 = 0; c4 < ncb; c4 += bcols)
                     for (int dr = 0; dr < 2; ++dr)
-                        for (int dc = 0; dc < 4; ++dc) {
+                        for (int dc = 0; dc < bcols; ++dc) {
                             const int rb = rp + dr, cb = c4 + dc;
                             if (rb < 0 || rb >= nrb || cb >= ncb) continue;
                             // only full 2x4 blocks first; ragged remainders are appended below
@@ -1039,7 +1174,25 @@ int build_plans(accbpg_dopt* h) {
     }
     ACC_HIP(hipMalloc(&h->tiles, sizeof(TileRC) * tl.size()));
     ACC_HIP(hipMemcpy(h->tiles, tl.data(), sizeof(TileRC) * tl.size(), hipMemcpyHostToDevice));
-    ACC_HIP(hipMalloc(&h->slabs, sizeof(double) * (size_t)grid * 2 * BM * BN));
+    // slab slots per workgroup = the most segments any workgroup walks through
+    {
+        int nslot = 1;
+        const int64_t half = h->kiters / 2;
+        for (int w = 0; w < grid; ++w) {
+            int64_t it = (int64_t)w * per;
+            const int64_t it1 = std::min(it + per, total);
+            int segs = 0;
+            while (it < it1) {
+                const int64_t e = it / h->kiters, off = it - e * h->kiters;
+                const int64_t end = (tl[(size_t)e].d1 < 0) ? h->kiters : (off >= half ? h->kiters : half);
+                it += std::min(end - off, it1 - it);
+                ++segs;
+            }
+            nslot = std::max(nslot, segs);
+        }
+        h->gram_nslot = nslot;
+    }
+    ACC_HIP(hipMalloc(&h->slabs, sizeof(double) * (size_t)grid * h->gram_nslot * BM * BN));
 
     // ---- inverse merge plan: binary tree over the NB-blocks of L
     const int T = (int)((m + NB - 1) / NB);
@@ -1108,21 +1261,21 @@ template <class T>
 static void gram_launch_t(accbpg_dopt* h, const double* x, double* gram) {
     prof_begin(h, PROF_GRAM);
     if constexpr (!T::EDGE && T::BM == 256) {
-        if (h->use_glds)
+        if (h->use_glds || h->has_duals)
             gram_streamk_glds_kernel<T><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
-                h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->slabs, gram, h->m);
+                h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->gram_nslot, h->slabs, gram, h->m);
         else
             gram_streamk_kernel<T><<<h->gram_grid, NTHREADS, T::LDS_BYTES, h->stream>>>(
-                h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->slabs, gram, h->m,
+                h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->gram_nslot, h->slabs, gram, h->m,
                 h->vec_ok);
     } else {
         gram_streamk_kernel<T><<<h->gram_grid, NTHREADS, T::LDS_BYTES, h->stream>>>(
-            h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->slabs, gram, h->m,
+            h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->gram_nslot, h->slabs, gram, h->m,
             h->vec_ok);
     }
     prof_end(h, PROF_GRAM);
     prof_begin(h, PROF_GRAMFIX);
-    gram_fixup_kernel<T><<<h->ntiles * T::MI, NTHREADS, 0, h->stream>>>(h->tiles, h->ntiles, h->kiters, h->gram_per,
+    gram_fixup_kernel<T><<<h->ntiles * 2 * T::MI * FIX_PJ, NTHREADS, 0, h->stream>>>(h->tiles, h->ntiles, h->kiters, h->gram_per, h->gram_nslot,
                                                                 h->slabs, gram, h->m, h->m);
     prof_end(h, PROF_GRAMFIX);
 }
@@ -1131,16 +1284,17 @@ static void gram_launch_t(accbpg_dopt* h, const double* x, double* gram) {
 int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, double* ms_out) {
     using T = TileBig<false, false>;
     if (!h->big) return ACCBPG_ERR_ARG;
+    if (h->has_duals && var < 10) return ACCBPG_ERR_ARG;     // the register-staged variants know no dual tiles
     hipEvent_t a, b;
     ACC_HIP(hipEventCreate(&a));
     ACC_HIP(hipEventCreate(&b));
     auto launch = [&]() {
 #define ACC_LAUNCH_VAR(VV)                                                                                       \
     gram_streamk_kernel<T, VV><<<h->gram_grid, NTHREADS, T::LDS_BYTES, h->stream>>>(                             \
-        h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->slabs, h->Tbuf, h->m, h->vec_ok)
+        h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->gram_nslot, h->slabs, h->Tbuf, h->m, h->vec_ok)
 #define ACC_LAUNCH_G(GG)                                                                                         \
     gram_streamk_glds_kernel<T, GG><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(                      \
-        h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->slabs, h->Tbuf, h->m)
+        h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->gram_nslot, h->slabs, h->Tbuf, h->m)
         switch (var) {
             case 10: ACC_LAUNCH_G(0); break;
             case 11: ACC_LAUNCH_G(1); break;
@@ -1176,16 +1330,23 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
 }
 
 int launch_gram(accbpg_dopt* h, const double* x, double* gram) {
-    const bool xal = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    bool xal = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (!xal && (h->has_duals || h->gram_mid)) {
+        // the tile list was built for the direct-to-LDS kernel, which reads x in 16-byte pieces
+        if (!h->xbuf) ACC_HIP(hipMalloc(&h->xbuf, sizeof(double) * (size_t)h->n));
+        ACC_HIP(hipMemcpyAsync(h->xbuf, x, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+        x = h->xbuf;
+        xal = true;
+    }
     if (h->gram_mid && xal) {
         using T = TileMid<false, false>;
         prof_begin(h, PROF_GRAM);
         gram_streamk_glds_kernel<T, 0, 2, 2><<<h->gram_grid, NTHREADS, 2 * T::G_STAGE * 8, h->stream>>>(
-            h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->slabs, gram, h->m);
+            h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->gram_nslot, h->slabs, gram, h->m);
         prof_end(h, PROF_GRAM);
         prof_begin(h, PROF_GRAMFIX);
-        gram_fixup_kernel<T><<<h->ntiles * T::MI, NTHREADS, 0, h->stream>>>(h->tiles, h->ntiles, h->kiters,
-                                                                            h->gram_per, h->slabs, gram, h->m, h->m);
+        gram_fixup_kernel<T><<<h->ntiles * 2 * T::MI * FIX_PJ, NTHREADS, 0, h->stream>>>(h->tiles, h->ntiles, h->kiters,
+                                                                            h->gram_per, h->gram_nslot, h->slabs, gram, h->m, h->m);
         prof_end(h, PROF_GRAMFIX);
         ACC_HIP(hipGetLastError());
         return ACCBPG_OK;

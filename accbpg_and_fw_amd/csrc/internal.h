@@ -38,8 +38,11 @@ struct GemmOp {
     double alpha, beta;
 };
 
+// entry of the Gram tile list: one BM x BN tile (d1 < 0), or a pair of 128 x 128 diagonal blocks d1, d2
+// (128-block indices) that run as "dual" tiles over half of K each (mfma_tile.hpp)
 struct TileRC {
     int32_t rb, cb;
+    int32_t d1 = -1, d2 = -1;
 };
 
 constexpr int NB = 64;          // Cholesky / inverse block size
@@ -73,12 +76,13 @@ struct accbpg_dopt {
     double* Tbuf = nullptr;     // m*m : scratch of the inverse merges / FW refactorisation
     double* slabs = nullptr;    // stream-K partial accumulators
     accbpg::TileRC* tiles = nullptr;
-    int ntiles = 0, gram_grid = 0, gram_per = 0;
+    int ntiles = 0, gram_grid = 0, gram_per = 0, gram_nslot = 2;
     int64_t kiters = 0;
     double* dscal = nullptr;    // device scalars
     int* dflag = nullptr;       // device status flags
     double* hpin = nullptr;     // pinned host mirror (scalars then flags)
     double* vws = nullptr;      // vector-kernel workspace
+    double* xbuf = nullptr;     // 16-byte aligned copy of an unaligned x (lazy)
 
     accbpg::GemmOp* ops = nullptr;            // device op table of the inverse merges
     std::vector<accbpg::GemmOp> ops_host;
@@ -93,6 +97,7 @@ struct accbpg_dopt {
     bool want_mid = false;      // Gram on 128x128 tiles, two workgroups per CU (set before build_plans)
     bool gram_mid = false;
     bool use_glds = true;       // direct-to-LDS staging for interior big tiles (debug switch)
+    bool has_duals = false;     // the Gram tile list holds dual diagonal tiles (direct-to-LDS kernel only)
     int chol_dbg = 0;           // timing ablation bits for chol_step_kernel (0 in production)
     bool prof_on = false;
     accbpg::ProfSlot prof[accbpg::PROF_COUNT];

@@ -315,6 +315,71 @@ struct Tile {
         }
     }
 
+    // ---- "dual" diagonal tile (Gram matrix only) ---------------------------------------------
+    // A 128 x 128 block ON the diagonal, G[band, band] = sum_k (V x)[band, k] V[band, k]^T, uses the same
+    // rows of V for both operands.  The 256-row A image then holds the band twice, at k-step ks (rows
+    // 0..127) and at k-step ks + K/2 (rows 128..255); the B fragments are read from the A image itself
+    // (rows 16j+lr of the matching half), no B image is loaded, and the two halves of the accumulators
+    // are partial sums over the two halves of K of the SAME 128 x 128 block -- all 32 MFMAs per fragment
+    // group do useful work for K/2 steps instead of half of them for K steps.
+    double fb2[2][NI];
+    __device__ __forceinline__ void glds_setup_A_dual(const double* __restrict__ V, int64_t ldv, int64_t band0,
+                                                      int64_t khalf) {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+        for (int p = 0; p < G_NA; ++p) {
+            const int q = wave + 4 * p;
+            const int row = 8 * q + (lane >> 3);                 // image row
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            gpa[p] = V + (band0 + (row & (BM / 2 - 1))) * ldv + 2 * c + ((row >= BM / 2) ? khalf : 0);
+        }
+    }
+    __device__ __forceinline__ void glds_issue_dual(int64_t ka, const double* __restrict__ x, int64_t khalf,
+                                                    double* __restrict__ stage) const {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+        for (int p = 0; p < G_NA; ++p) glds16(gpa[p] + ka, stage + (wave + 4 * p) * 128);
+        // one 256-byte piece: lanes 0..31 bring x[ka .. ka+15], lanes 32..63 x[ka+khalf .. +15]
+        const float* sx = reinterpret_cast<const float*>(x + ka + ((lane & 32) ? khalf : 0)) + (lane & 31);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx,
+                                         (__attribute__((address_space(3))) void*)(stage + G_A + G_B), 4, 0, 0);
+    }
+    static constexpr int G_NLD_DUAL = G_NA + 1;
+    template <int SET>
+    __device__ __forceinline__ void read_frag_dual(const double* __restrict__ stage, int kk) {
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int lr = lane & 15, lq = lane >> 4;
+        const int sw = (lr >> 1) & 7;
+        const int koff = 2 * ((2 * kk + (lq >> 1)) ^ sw) + (lq & 1);
+        const double* as = stage + (16 * wave + lr) * BK + koff;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[SET][i] = as[i * 16 * WAVES_M * BK];
+        const double* bs = stage + lr * BK + koff;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            fb[SET][j] = bs[j * 16 * BK];
+            fb2[SET][j] = bs[(BM / 2 + j * 16) * BK];
+        }
+        const double x1 = stage[G_A + G_B + 4 * kk + lq], x2 = stage[G_A + G_B + 16 + 4 * kk + lq];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[SET][i] *= (i < MI / 2) ? x1 : x2;
+    }
+    // Fragment (i, j) of the diagonal block covers rows 64*(i mod MI/2) + 16*wave .. +15 and columns
+    // 16j .. 16j+15: it lies strictly above the diagonal, and is skipped, when j > 4*(i mod MI/2) + wave.
+    template <int SET>
+    __device__ __forceinline__ void mma_dual() {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int lim = (16 * WAVES_M / 16) * (i % (MI / 2)) + wave;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                if (j > lim) break;
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET][i], (i < MI / 2) ? fb[SET][j] : fb2[SET][j],
+                                                                 acc[i][j], 0, 0, 0);
+            }
+        }
+    }
     // ---- epilogues -----------------------------------------------------------------------
     // C[row][col] = alpha*acc + beta*C, guarded; lower_only drops elements with col > row.
     __device__ __forceinline__ void store_C(double* __restrict__ C, int64_t ldc, int64_t row0, int64_t col0,
@@ -372,20 +437,29 @@ struct Tile {
                 for (int r = 0; r < 4; ++r) acc[i][j][r] += slab[((i * NI + j) * 4 + r) * NTHREADS + tid];
     }
     static constexpr int SLAB_DOUBLES = MI * NI * 4 * NTHREADS;   // == BM*BN
-    // fix-up on a quarter-tile: only fragment row `part` (of MI) is summed and stored
-    __device__ __forceinline__ void add_slab_part(const double* __restrict__ slab, int part) {
+    // fix-up on a piece of a tile: fragment row `part` (of MI), column fragments [j0, j1)
+    __device__ __forceinline__ void add_slab_part(const double* __restrict__ slab, int part, int j0 = 0,
+                                                  int j1 = NI) {
+        add_slab_part_to(slab, part, part, j0, j1);
+    }
+    // dual tiles: fragment row `src` of a slab is a partial sum of output fragment row `dst`
+    __device__ __forceinline__ void add_slab_part_to(const double* __restrict__ slab, int src, int dst, int j0 = 0,
+                                                     int j1 = NI) {
         const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
-            if (i == part) {
+            if (i == dst) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
+                    if (j >= j0 && j < j1) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] += slab[((i * NI + j) * 4 + r) * NTHREADS + tid];
+                        for (int r = 0; r < 4; ++r) acc[i][j][r] += slab[((src * NI + j) * 4 + r) * NTHREADS + tid];
+                    }
             }
     }
     __device__ __forceinline__ void store_C_part(double* __restrict__ C, int64_t ldc, int64_t row0, int64_t col0,
-                                                 int64_t M, int64_t N, bool lower_only, int part) const {
+                                                 int64_t M, int64_t N, bool lower_only, int part, int j0 = 0,
+                                                 int j1 = NI) const {
         const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const int wm = wave / WAVES_N, wn = wave % WAVES_N;
         const int lr = lane & 15, lq = lane >> 4;
@@ -394,11 +468,13 @@ struct Tile {
             if (i == part) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
+                    if (j >= j0 && j < j1) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int64_t row = row0 + 16 * (i * WAVES_M + wm) + lq + 4 * r;
-                        const int64_t col = col0 + wn * WN + 16 * j + lr;
-                        if (row < M && col < N && !(lower_only && col > row)) C[row * ldc + col] = acc[i][j][r];
+                        for (int r = 0; r < 4; ++r) {
+                            const int64_t row = row0 + 16 * (i * WAVES_M + wm) + lq + 4 * r;
+                            const int64_t col = col0 + wn * WN + 16 * j + lr;
+                            if (row < M && col < N && !(lower_only && col > row)) C[row * ldc + col] = acc[i][j][r];
+                        }
                     }
             }
     }

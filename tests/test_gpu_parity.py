@@ -80,9 +80,12 @@ def test_func_grad_matches_reference_golden(acc, O, tag):
 
 
 @pytest.mark.parametrize("shape", [(13, 506, 0), (80, 200, 10), (100, 1001, 4), (333, 777, 5),
-                                   (768, 2048, 6), (1024, 4096, 8), (1000, 3000, 9)])
+                                   (768, 2048, 6), (1024, 4096, 8), (1000, 3000, 9), (1280, 2560, 11),
+                                   (1024, 4112, 12), (2304, 4608, 13), (1536, 2080, 14)])
 def test_func_grad_matches_oracle_ragged_sizes(acc, O, shape):
-    """Sizes that are not tile multiples (odd n, odd m, big tile with edges)."""
+    """Sizes that are not tile multiples (odd n, odd m, big tile with edges); interior sizes whose
+    Gram tile list holds dual diagonal tiles (even / odd count of them, short and long K ranges per
+    workgroup) and one with an odd number of k-steps, where the list stays plain."""
     m, n, seed = shape
     V = gaussian_design(m, n, seed + 100)
     rng = np.random.RandomState(seed)
@@ -94,6 +97,28 @@ def test_func_grad_matches_oracle_ragged_sizes(acc, O, shape):
     fr, gr = fo.func_grad(x, 2)
     assert abs(fx - fr) < 1e-11 * max(1.0, abs(fr))
     np.testing.assert_allclose(g, gr, rtol=1e-11, atol=0)
+
+
+def test_gram_unaligned_x_through_c_abi(acc, O):
+    """An x that is only 8-byte aligned on an instance whose Gram tile list holds dual tiles (the
+    direct-to-LDS kernel reads x in 16-byte pieces): the library stages an aligned copy."""
+    from accbpg_and_fw_amd import _lib
+    lib = _lib.load()
+    m, n = 1024, 2048
+    V = gaussian_design(m, n, 321)
+    rng = np.random.RandomState(1)
+    x = rng.rand(n) + 0.01
+    x /= x.sum()
+    f = acc.DOptimalObj(V)
+    buf = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+    buf[1:] = dev(x)
+    g = torch.empty(n, dtype=torch.float64, device="cuda")
+    fv = C.c_double()
+    assert lib.accbpg_dopt_func_grad(f._h, buf.data_ptr() + 8, 2, C.byref(fv), g.data_ptr()) == 0
+    torch.cuda.synchronize()
+    fr, gr = O.DOptOracle(V).func_grad(x, 2)
+    assert abs(fv.value - fr) < 1e-11 * abs(fr)
+    np.testing.assert_allclose(g.cpu().numpy(), gr, rtol=1e-11)
 
 
 def test_func_grad_errors(acc):
