@@ -183,17 +183,17 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
                     if (nx2 >= 3) nx2 -= 3;
                     const double* st = lds + cur * T::G_STAGE;
                     t.template read_frag_dual<1>(st, 1);
-                    t.template mma_dual<0>();
+                    t.template scale_dual<0>(); t.template mma_dual<0>();
                     t.glds_issue_dual(min(ks + 2, klast) * BK, x, khalf, lds + nx2 * T::G_STAGE);
                     t.template read_frag_dual<0>(st, 2);
-                    t.template mma_dual<1>();
+                    t.template scale_dual<1>(); t.template mma_dual<1>();
                     t.template read_frag_dual<1>(st, 3);
-                    t.template mma_dual<0>();
+                    t.template scale_dual<0>(); t.template mma_dual<0>();
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLDD) : "memory");
                     __builtin_amdgcn_s_barrier();
                     cur = (cur + 1 == 3) ? 0 : cur + 1;
                     t.template read_frag_dual<0>(lds + cur * T::G_STAGE, 0);
-                    t.template mma_dual<1>();
+                    t.template scale_dual<1>(); t.template mma_dual<1>();
                 }
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
                 // always through a slab: the fix-up adds the two K halves (fragment rows i and i + MI/2)
@@ -221,18 +221,47 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
             // stage are read right behind it and land while those 32 MFMAs occupy the matrix pipe, so
             // the pipe has work queued across the barrier instead of waiting out an LDS round trip.
             t.template read_frag_g<0, true>(lds, 0);
+            // The schedule is pinned (sched_barrier): fragment reads of the next group first, then the
+            // x-scaling of the set that is about to be used (requested a whole group earlier), then the
+            // MFMAs; the loads of stage ks+2 are dealt out between the fragment rows of group 0.
+            static_assert(T::MI == 4, "group 0 is dealt out over four fragment rows");
+            constexpr int NP = T::G_NA + T::G_NB;
+            constexpr int P1 = (NP + 2) / 3, P2 = 2 * P1 < NP ? 2 * P1 : NP;
 #pragma unroll 1
             for (int64_t ks = kb; ks < ke; ++ks) {
                 int nx2 = cur + 2;
                 if (nx2 >= 3) nx2 -= 3;
                 const double* st = lds + cur * T::G_STAGE;
+                double* nst = lds + nx2 * T::G_STAGE;            // last read in step ks-1
+                const int64_t k2 = min(ks + 2, klast) * BK;
+                // (the scaling multiplies come BEFORE the next reads are issued: the wait in front of
+                //  them then covers only reads that were issued a whole group ago)
+                t.template scale_frag<0>();
+                __builtin_amdgcn_sched_barrier(0);
                 t.template read_frag_g<1, true>(st, 1);
-                t.template mma_frag<0>();
-                if constexpr (!(GV & 1)) issue(min(ks + 2, klast), nx2);   // that buffer was last read in step ks-1
+                __builtin_amdgcn_sched_barrier(0);
+                t.template mma_row<0>(0);
+                if constexpr (!(GV & 1)) t.glds_issue_range(k2, k2, nst, 0, P1);
+                t.template mma_row<0>(1);
+                if constexpr (!(GV & 1)) t.glds_issue_range(k2, k2, nst, P1, P2);
+                t.template mma_row<0>(2);
+                if constexpr (!(GV & 1)) { t.glds_issue_range(k2, k2, nst, P2, NP); t.glds_x(x, k2, nst); }
+                t.template mma_row<0>(3);
+                __builtin_amdgcn_sched_barrier(0);
+                t.template scale_frag<1>();
+                __builtin_amdgcn_sched_barrier(0);
                 t.template read_frag_g<0, true>(st, 2);
+                __builtin_amdgcn_sched_barrier(0);
                 t.template mma_frag<1>();
+                __builtin_amdgcn_sched_barrier(0);
+                t.template scale_frag<0>();
+                __builtin_amdgcn_sched_barrier(0);
                 t.template read_frag_g<1, true>(st, 3);
+                __builtin_amdgcn_sched_barrier(0);
                 t.template mma_frag<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                t.template scale_frag<1>();
+                __builtin_amdgcn_sched_barrier(0);
                 // stage ks+1 (issued one step ago) must have landed: all but the newest NLD loads done;
                 // lgkmcnt(0): this wave's reads of stage ks are complete before others may overwrite it
                 if constexpr (!(GV & 2)) {
@@ -242,7 +271,9 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
                 cur = (cur + 1 == 3) ? 0 : cur + 1;
                 // (after the last step this reads the redundant, already landed copy of stage klast)
                 t.template read_frag_g<0, true>(lds + cur * T::G_STAGE, 0);
+                __builtin_amdgcn_sched_barrier(0);
                 t.template mma_frag<1>();
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             issue(kb, 0);
@@ -255,12 +286,12 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
                 const double* st = lds + cur * T::G_STAGE;
                 t.template read_frag_g<0, true>(st, 0);
                 t.template read_frag_g<1, true>(st, 1);
-                t.template mma_frag<0>();
+                t.template scale_frag<0>(); t.template mma_frag<0>();
                 t.template read_frag_g<0, true>(st, 2);
-                t.template mma_frag<1>();
+                t.template scale_frag<1>(); t.template mma_frag<1>();
                 t.template read_frag_g<1, true>(st, 3);
-                t.template mma_frag<0>();
-                t.template mma_frag<1>();
+                t.template scale_frag<0>(); t.template mma_frag<0>();
+                t.template scale_frag<1>(); t.template mma_frag<1>();
                 // stage ks+1 has landed and every wave is done reading stage ks ...
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();

@@ -204,6 +204,25 @@ struct Tile {
             }
         }
     }
+    // one fragment row of a group (NI MFMAs): lets the caller place other instructions between rows
+    template <int SET>
+    __device__ __forceinline__ void mma_row(int i_rt, int mi_lo = 0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+            if (i == i_rt && i >= mi_lo) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);
+            }
+    }
+    // x[k] of the fragment set (weighted Gram matrix), applied by scale_frag right before the set is used:
+    // the multiply then waits for data that was requested a whole MFMA group earlier
+    double fx[2];
+    template <int SET>
+    __device__ __forceinline__ void scale_frag() {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[SET][i] *= fx[SET];
+    }
     // whole 16-deep stage, no overlap with staging (small / latency-bound users)
     __device__ __forceinline__ void compute(const double* __restrict__ stage, int mi_lo = 0) {
         read_frag<0>(stage, 0);
@@ -237,47 +256,80 @@ struct Tile {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
-    // per-lane source pointers of the pieces this wave moves, for k-step 0 (set once per tile
-    // segment; a k-step only adds a scalar offset)
-    const double* gpa[G_NA];
-    const double* gpb[G_NB];
+    // per-lane BYTE offsets of the pieces this wave moves, relative to the uniform base pointers of k-step 0
+    // (set once per tile segment).  A k-step adds a scalar to the base only, so the load takes the
+    // "scalar base + 32-bit lane offset" addressing form and needs no vector address arithmetic.
+    uint32_t goa[G_NA];
+    uint32_t gob[G_NB];
+    const char* gbase_a;
+    const char* gbase_b;
     __device__ __forceinline__ void glds_setup_A(const double* __restrict__ A, int64_t lda, int64_t row0) {
         const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        gbase_a = reinterpret_cast<const char*>(A + row0 * lda);
 #pragma unroll
         for (int p = 0; p < G_NA; ++p) {
             const int q = wave + 4 * p;                          // 1-KiB piece = rows 8q .. 8q+7
             const int row = 8 * q + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
-            gpa[p] = A + (row0 + row) * lda + 2 * c;
+            goa[p] = (uint32_t)(((int64_t)row * lda + 2 * c) * 8);
         }
     }
     __device__ __forceinline__ void glds_setup_B_kc(const double* __restrict__ B, int64_t ldb, int64_t col0) {
         const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        gbase_b = reinterpret_cast<const char*>(B + col0 * ldb);
 #pragma unroll
         for (int p = 0; p < G_NB; ++p) {
             const int q = wave + 4 * p;
             const int row = 8 * q + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
-            gpb[p] = B + (col0 + row) * ldb + 2 * c;
+            gob[p] = (uint32_t)(((int64_t)row * ldb + 2 * c) * 8);
         }
     }
     __device__ __forceinline__ void glds_setup_B_km(const double* __restrict__ B, int64_t ldb, int64_t col0) {
         static_assert(!BKM || BN == 128, "one 1-KiB piece per k-row");
         const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        gbase_b = reinterpret_cast<const char*>(B + col0);
 #pragma unroll
         for (int p = 0; p < G_NB; ++p) {
             const int kr = wave + 4 * p;                         // k-row of the tile
             const int c = lane ^ (8 * (kr & 1));                 // source chunk (2 columns) for LDS chunk `lane`
-            gpb[p] = B + (int64_t)kr * ldb + col0 + 2 * c;
+            gob[p] = (uint32_t)(((int64_t)kr * ldb + 2 * c) * 8);
         }
     }
     // issue the pieces of one k-step: ka / kb = element offsets of that step in A / B
     __device__ __forceinline__ void glds_issue(int64_t ka, int64_t kb, double* __restrict__ stage) const {
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const char* ba = gbase_a + ka * 8;
+        const char* bb = gbase_b + kb * 8;
+        // (the empty asm keeps the 32-bit offset's zero-extension next to its use: hoisted out of the k-loop
+        //  it would turn into a 64-bit vector add per load instead of the scalar-base form)
 #pragma unroll
-        for (int p = 0; p < G_NA; ++p) glds16(gpa[p] + ka, stage + (wave + 4 * p) * 128);
+        for (int p = 0; p < G_NA; ++p) {
+            uint32_t o = goa[p];
+            asm volatile("" : "+v"(o));
+            glds16(reinterpret_cast<const double*>(ba + o), stage + (wave + 4 * p) * 128);
+        }
 #pragma unroll
-        for (int p = 0; p < G_NB; ++p) glds16(gpb[p] + kb, stage + G_A + (wave + 4 * p) * 128);
+        for (int p = 0; p < G_NB; ++p) {
+            uint32_t o = gob[p];
+            asm volatile("" : "+v"(o));
+            glds16(reinterpret_cast<const double*>(bb + o), stage + G_A + (wave + 4 * p) * 128);
+        }
+    }
+    // pieces [p0, p1) of the combined list (A pieces first, then B pieces) of one k-step
+    __device__ __forceinline__ void glds_issue_range(int64_t ka, int64_t kb, double* __restrict__ stage, int p0,
+                                                     int p1) const {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const char* ba = gbase_a + ka * 8;
+        const char* bb = gbase_b + kb * 8;
+#pragma unroll
+        for (int p = 0; p < G_NA + G_NB; ++p)
+            if (p >= p0 && p < p1) {
+                uint32_t o = (p < G_NA) ? goa[p < G_NA ? p : 0] : gob[p >= G_NA ? p - G_NA : 0];
+                asm volatile("" : "+v"(o));
+                const char* b = (p < G_NA) ? ba : bb;
+                glds16(reinterpret_cast<const double*>(b + o), stage + (p < G_NA ? 0 : G_A) + (wave + 4 * (p < G_NA ? p : p - G_NA)) * 128);
+            }
     }
     // 32 doubles of x (16 used) behind the images; every wave writes the same bytes so that all
     // waves carry the same number of outstanding loads
@@ -308,11 +360,7 @@ struct Tile {
 #pragma unroll
             for (int j = 0; j < NI; ++j) fb[SET][j] = bs[j * 16 * BK];
         }
-        if constexpr (SCALE) {
-            const double xk = stage[G_A + G_B + 4 * kk + lq];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) fa[SET][i] *= xk;
-        }
+        if constexpr (SCALE) fx[SET] = stage[G_A + G_B + 4 * kk + lq];   // applied by scale_frag<SET>()
     }
 
     // ---- "dual" diagonal tile (Gram matrix only) ---------------------------------------------
@@ -326,19 +374,25 @@ struct Tile {
     __device__ __forceinline__ void glds_setup_A_dual(const double* __restrict__ V, int64_t ldv, int64_t band0,
                                                       int64_t khalf) {
         const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        gbase_a = reinterpret_cast<const char*>(V + band0 * ldv);
 #pragma unroll
         for (int p = 0; p < G_NA; ++p) {
             const int q = wave + 4 * p;
             const int row = 8 * q + (lane >> 3);                 // image row
             const int c = (lane & 7) ^ ((row >> 1) & 7);
-            gpa[p] = V + (band0 + (row & (BM / 2 - 1))) * ldv + 2 * c + ((row >= BM / 2) ? khalf : 0);
+            goa[p] = (uint32_t)(((int64_t)(row & (BM / 2 - 1)) * ldv + 2 * c + ((row >= BM / 2) ? khalf : 0)) * 8);
         }
     }
     __device__ __forceinline__ void glds_issue_dual(int64_t ka, const double* __restrict__ x, int64_t khalf,
                                                     double* __restrict__ stage) const {
         const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const char* ba = gbase_a + ka * 8;
 #pragma unroll
-        for (int p = 0; p < G_NA; ++p) glds16(gpa[p] + ka, stage + (wave + 4 * p) * 128);
+        for (int p = 0; p < G_NA; ++p) {
+            uint32_t o = goa[p];
+            asm volatile("" : "+v"(o));
+            glds16(reinterpret_cast<const double*>(ba + o), stage + (wave + 4 * p) * 128);
+        }
         // one 256-byte piece: lanes 0..31 bring x[ka .. ka+15], lanes 32..63 x[ka+khalf .. +15]
         const float* sx = reinterpret_cast<const float*>(x + ka + ((lane & 32) ? khalf : 0)) + (lane & 31);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sx,
@@ -360,9 +414,14 @@ struct Tile {
             fb[SET][j] = bs[j * 16 * BK];
             fb2[SET][j] = bs[(BM / 2 + j * 16) * BK];
         }
-        const double x1 = stage[G_A + G_B + 4 * kk + lq], x2 = stage[G_A + G_B + 16 + 4 * kk + lq];
+        fx[SET] = stage[G_A + G_B + 4 * kk + lq];
+        fx2[SET] = stage[G_A + G_B + 16 + 4 * kk + lq];
+    }
+    double fx2[2];
+    template <int SET>
+    __device__ __forceinline__ void scale_dual() {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) fa[SET][i] *= (i < MI / 2) ? x1 : x2;
+        for (int i = 0; i < MI; ++i) fa[SET][i] *= (i < MI / 2) ? fx[SET] : fx2[SET];
     }
     // Fragment (i, j) of the diagonal block covers rows 64*(i mod MI/2) + 16*wave .. +15 and columns
     // 16j .. 16j+15: it lies strictly above the diagonal, and is skipped, when j > 4*(i mod MI/2) + wave.
