@@ -182,18 +182,34 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
                     int nx2 = cur + 2;
                     if (nx2 >= 3) nx2 -= 3;
                     const double* st = lds + cur * T::G_STAGE;
+                    t.template scale_dual<0>();
+                    __builtin_amdgcn_sched_barrier(0);
                     t.template read_frag_dual<1>(st, 1);
-                    t.template scale_dual<0>(); t.template mma_dual<0>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    t.template mma_dual<0>();
                     t.glds_issue_dual(min(ks + 2, klast) * BK, x, khalf, lds + nx2 * T::G_STAGE);
+                    __builtin_amdgcn_sched_barrier(0);
+                    t.template scale_dual<1>();
+                    __builtin_amdgcn_sched_barrier(0);
                     t.template read_frag_dual<0>(st, 2);
-                    t.template scale_dual<1>(); t.template mma_dual<1>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    t.template mma_dual<1>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    t.template scale_dual<0>();
+                    __builtin_amdgcn_sched_barrier(0);
                     t.template read_frag_dual<1>(st, 3);
-                    t.template scale_dual<0>(); t.template mma_dual<0>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    t.template mma_dual<0>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    t.template scale_dual<1>();
+                    __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLDD) : "memory");
                     __builtin_amdgcn_s_barrier();
                     cur = (cur + 1 == 3) ? 0 : cur + 1;
                     t.template read_frag_dual<0>(lds + cur * T::G_STAGE, 0);
-                    t.template scale_dual<1>(); t.template mma_dual<1>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    t.template mma_dual<1>();
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
                 // always through a slab: the fix-up adds the two K halves (fragment rows i and i + MI/2)
@@ -528,19 +544,39 @@ __global__ __launch_bounds__(NTHREADS, 1) void colnorm_glds_kernel(
                 const int64_t num = kd - 15 - 16 * wm;
                 mi_lo = num > 0 ? (int)((num + 16 * T::WAVES_M - 1) / (16 * T::WAVES_M)) : 0;
             }
+            // pinned schedule as in the Gram kernel: reads of the next group, then the MFMAs, the loads
+            // of stage ks+2 dealt out between the fragment rows of group 0
+            constexpr int NP = T::G_NA + T::G_NB;
+            constexpr int P1 = (NP + 2) / 3, P2 = 2 * P1 < NP ? 2 * P1 : NP;
+            static_assert(T::MI == 4, "group 0 is dealt out over four fragment rows");
+            double* nst = lds + nx2 * T::G_STAGE;
+            const int64_t k2 = min(ks + 2, klast) * BK;
             t.template read_frag_g<1, false>(st, 1);
-            t.template mma_frag<0>(mi_lo);
-            issue(min(ks + 2, klast), nx2);
+            __builtin_amdgcn_sched_barrier(0);
+            t.template mma_row<0>(0, mi_lo);
+            t.glds_issue_range(k2, k2 * ldv, nst, 0, P1);
+            t.template mma_row<0>(1, mi_lo);
+            t.glds_issue_range(k2, k2 * ldv, nst, P1, P2);
+            t.template mma_row<0>(2, mi_lo);
+            t.glds_issue_range(k2, k2 * ldv, nst, P2, NP);
+            t.template mma_row<0>(3, mi_lo);
+            __builtin_amdgcn_sched_barrier(0);
             t.template read_frag_g<0, false>(st, 2);
+            __builtin_amdgcn_sched_barrier(0);
             t.template mma_frag<1>(mi_lo);
+            __builtin_amdgcn_sched_barrier(0);
             t.template read_frag_g<1, false>(st, 3);
+            __builtin_amdgcn_sched_barrier(0);
             t.template mma_frag<0>(mi_lo);
+            __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLD) : "memory");
             __builtin_amdgcn_s_barrier();
             cur = (cur + 1 == 3) ? 0 : cur + 1;
-            // first fragments of the next stage land under the last group's MFMAs (see the Gram kernel)
+            // first fragments of the next stage land under the last group's MFMAs
             t.template read_frag_g<0, false>(lds + cur * T::G_STAGE, 0);
+            __builtin_amdgcn_sched_barrier(0);
             t.template mma_frag<1>(mi_lo);
+            __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
