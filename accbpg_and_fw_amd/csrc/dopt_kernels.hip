@@ -141,7 +141,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_kernel(
 // Direct-to-LDS version of the Gram kernel for interior tiles (same stream-K decomposition and
 // slabs): global_load_lds_dwordx4 into three rotating swizzled stages, loads two k-steps ahead,
 // counted vmcnt + raw barrier, x applied to the A fragments after the LDS read.
-// GV (timing ablations only): bit 0 = no loads inside the k-loop, bit 1 = no wait + barrier.
+// GV (timing ablations only): bit 0 = no loads inside the k-loop, bit 1 = no wait + barrier,
+// bit 2 = no fragment reads, bit 3 = barrier without the vmcnt wait.
 // NSTAGE = 3: loads two k-steps ahead, one workgroup per CU (big tile);
 // NSTAGE = 2: loads one k-step ahead, issued right after the barrier into the buffer just read --
 //             for the mid tile at two workgroups per CU, where the co-resident workgroup hides the waits.
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
                 //  them then covers only reads that were issued a whole group ago)
                 t.template scale_frag<0>();
                 __builtin_amdgcn_sched_barrier(0);
-                t.template read_frag_g<1, true>(st, 1);
+                if constexpr (!(GV & 4)) t.template read_frag_g<1, true>(st, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 t.template mma_row<0>(0);
                 if constexpr (!(GV & 1)) t.glds_issue_range(k2, k2, nst, 0, P1);
@@ -266,13 +267,13 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
                 __builtin_amdgcn_sched_barrier(0);
                 t.template scale_frag<1>();
                 __builtin_amdgcn_sched_barrier(0);
-                t.template read_frag_g<0, true>(st, 2);
+                if constexpr (!(GV & 4)) t.template read_frag_g<0, true>(st, 2);
                 __builtin_amdgcn_sched_barrier(0);
                 t.template mma_frag<1>();
                 __builtin_amdgcn_sched_barrier(0);
                 t.template scale_frag<0>();
                 __builtin_amdgcn_sched_barrier(0);
-                t.template read_frag_g<1, true>(st, 3);
+                if constexpr (!(GV & 4)) t.template read_frag_g<1, true>(st, 3);
                 __builtin_amdgcn_sched_barrier(0);
                 t.template mma_frag<0>();
                 __builtin_amdgcn_sched_barrier(0);
@@ -281,12 +282,13 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
                 // stage ks+1 (issued one step ago) must have landed: all but the newest NLD loads done;
                 // lgkmcnt(0): this wave's reads of stage ks are complete before others may overwrite it
                 if constexpr (!(GV & 2)) {
-                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLD) : "memory");
+                    if constexpr (GV & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLD) : "memory");
                     __builtin_amdgcn_s_barrier();
                 }
                 cur = (cur + 1 == 3) ? 0 : cur + 1;
                 // (after the last step this reads the redundant, already landed copy of stage klast)
-                t.template read_frag_g<0, true>(lds + cur * T::G_STAGE, 0);
+                if constexpr (!(GV & 4)) t.template read_frag_g<0, true>(lds + cur * T::G_STAGE, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 t.template mma_frag<1>();
                 __builtin_amdgcn_sched_barrier(0);
@@ -902,6 +904,195 @@ __device__ __forceinline__ void potrf64_lds(const double* __restrict__ S, double
     __syncthreads();
 }
 
+// value of lane `SRC` of each 16-lane row, in every lane of that row (DPP row_newbcast, no SGPR round trip)
+template <int SRC>
+__device__ __forceinline__ double row_bcast(double v) {
+    constexpr int ctrl = 0x150 + SRC;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int J, int C>
+__device__ __forceinline__ void potrf16_rest(double (&a)[16], double l) {
+    if constexpr (C < 16) {
+        a[C] = fma(-l, row_bcast<C>(l), a[C]);
+        potrf16_rest<J, C + 1>(a, l);
+    }
+}
+template <int J>
+__device__ __forceinline__ void potrf16_step(double (&a)[16], int r, int k0, int bs, double& dsv, double& myrs,
+                                             double& minp) {
+    const double piv = row_bcast<J>(a[J]);
+    minp = fmin(minp, (k0 + J < bs) ? piv : 1.0);
+    const double rs = rsqrt_newton(piv);     // a non-positive pivot turns the block into NaNs; minp reports it
+    const double l = a[J] * rs;
+    dsv = (r == J) ? piv : dsv;
+    myrs = (r == J) ? rs : myrs;
+    a[J] = l;
+    if constexpr (J + 1 < 16) {
+        // the entry that becomes the next pivot first
+        a[J + 1] = fma(-l, row_bcast<J + 1>(l), a[J + 1]);
+    }
+    potrf16_rest<J, J + 2>(a, l);
+}
+// Blocked factorisation of the 64x64 block image S (lower, identity-padded beyond bs) into Lo, in four
+// panels of 16 columns:
+//   A  one wavefront factors the 16x16 diagonal block with a row per lane in registers -- the pivot and
+//      the column entries travel by v_readlane, no LDS round trip and no barrier inside the 16 steps;
+//   B  the rows below solve against it, a thread per row, the 16x16 factor read as LDS broadcasts;
+//   C  the trailing blocks take their rank-16 update on the MFMA pipe.
+// Three barriers per panel instead of one per column; the serial chain is 64 register-resident steps.
+// `tbuf`: 4 * POTRF_TB doubles of scratch.  Lo gets the lower triangle, zeros above it.
+constexpr int POTRF_TB = 16 * 16 + 16;
+__device__ __forceinline__ void potrf64_blk(double* __restrict__ S, double* __restrict__ Lo,
+                                            double* __restrict__ tbuf, int* __restrict__ badflag, int bs) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // per panel: lt[c*16 + cc] = L16[cc][c] (column c of the panel's diagonal factor), rv[c] = 1 / L16[c][c];
+    // all four panels' copies stay in tbuf for the panel solve that follows (trsm64_blk)
+    // zero the six 16x16 blocks of Lo above the diagonal blocks (nothing below writes them)
+    for (int e = tid; e < 6 * 256; e += NTHREADS) {
+        const int b = e >> 8, w = e & 255;                       // b: (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+        const int br = (b < 3) ? 0 : ((b < 5) ? 1 : 2);
+        const int bc = (b < 3) ? b + 1 : ((b < 5) ? b - 1 : 3);
+        Lo[(16 * br + (w >> 4)) * SP + 16 * bc + (w & 15)] = 0.0;
+    }
+#pragma unroll 1
+    for (int pnl = 0; pnl < NB / 16; ++pnl) {
+        const int k0 = 16 * pnl;
+        double* lt = tbuf + pnl * POTRF_TB;
+        double* rv = lt + 256;
+        // ---- A: 16x16 diagonal block on wavefront 0 (every lane l works on row l & 15)
+        if (wave == 0) {
+            const int r = lane & 15;
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[c] = S[(k0 + r) * SP + k0 + c];
+            double dsv = 1.0, myrs = 1.0, minp = 1.0;
+            potrf16_step<0>(a, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<1>(a, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<2>(a, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<3>(a, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<4>(a, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<5>(a, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<6>(a, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<7>(a, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<8>(a, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<9>(a, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<10>(a, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<11>(a, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<12>(a, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<13>(a, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<14>(a, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<15>(a, r, k0, bs, dsv, myrs, minp);
+            const bool bad = !(minp > 0.0);
+            const double dg = sqrt(dsv);
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const double v = (c < r) ? a[c] : ((c == r) ? dg : 0.0);
+                    Lo[(k0 + r) * SP + k0 + c] = v;
+                    lt[c * 16 + r] = v;
+                }
+                rv[r] = myrs;
+                if (bad) *badflag = 1;
+            }
+        }
+        __syncthreads();
+        if (pnl == NB / 16 - 1) break;
+        // ---- B: rows below the diagonal block: x L16^T = p, one thread per row
+        const int nrows = NB - k0 - 16;
+        if (tid < nrows) {
+            const int row = k0 + 16 + tid;
+            double pr[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) pr[c] = S[row * SP + k0 + c];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const double xc = pr[c] * rv[c];
+                pr[c] = xc;
+#pragma unroll
+                for (int cc = c + 1; cc < 16; ++cc) pr[cc] = fma(-xc, lt[c * 16 + cc], pr[cc]);
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) Lo[row * SP + k0 + c] = pr[c];
+        }
+        __syncthreads();
+        // ---- C: trailing update S(bi,bj) -= X_bi X_bj^T on the MFMA pipe, 16x16 blocks bi >= bj > pnl
+        {
+            const int nb = NB / 16 - 1 - pnl;                      // remaining 16-blocks per dimension
+            const int nblk = nb * (nb + 1) / 2;
+            const int lr = lane & 15, lq = lane >> 4;
+            for (int b = wave; b < nblk; b += NTHREADS / 64) {
+                int bi = 0;
+                while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+                const int bj = b - bi * (bi + 1) / 2;
+                const int ri = 16 * (pnl + 1 + bi), rj = 16 * (pnl + 1 + bj);
+                d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double av = Lo[(ri + lr) * SP + k0 + 4 * kk + lq];
+                    const double bv = Lo[(rj + lr) * SP + k0 + 4 * kk + lq];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) S[(ri + lq + 4 * rr) * SP + rj + lr] -= acc[rr];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Solve X * L^T = P for the 64 rows of Xs in place with the factor potrf64_blk left in Lo / tbuf, in four
+// panels of 16 columns: a thread per row substitutes against the 16x16 diagonal factor (LDS broadcasts),
+// then the columns to the right take their rank-16 update on the MFMA pipe.  Two barriers per panel.
+__device__ __forceinline__ void trsm64_blk(double* __restrict__ Xs, const double* __restrict__ Lo,
+                                           const double* __restrict__ tbuf) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll 1
+    for (int pnl = 0; pnl < NB / 16; ++pnl) {
+        const int k0 = 16 * pnl;
+        const double* lt = tbuf + pnl * POTRF_TB;
+        const double* rv = lt + 256;
+        if (wave == 0) {
+            double pr[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) pr[c] = Xs[lane * SP + k0 + c];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const double xc = pr[c] * rv[c];
+                pr[c] = xc;
+#pragma unroll
+                for (int cc = c + 1; cc < 16; ++cc) pr[cc] = fma(-xc, lt[c * 16 + cc], pr[cc]);
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) Xs[lane * SP + k0 + c] = pr[c];
+        }
+        if (pnl == NB / 16 - 1) break;
+        __syncthreads();
+        {
+            // P(:, 16q ..) -= X_p L(16q .., k0 .. k0+15)^T for the column blocks q > pnl, 16 x 16 pieces
+            const int ncb = NB / 16 - 1 - pnl;
+            const int lr = lane & 15, lq = lane >> 4;
+            for (int b = wave; b < 4 * ncb; b += NTHREADS / 64) {
+                const int bi = b & 3, q = pnl + 1 + (b >> 2);
+                d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double av = Xs[(16 * bi + lr) * SP + k0 + 4 * kk + lq];
+                    const double bv = Lo[(16 * q + lr) * SP + k0 + 4 * kk + lq];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) Xs[(16 * bi + lq + 4 * rr) * SP + 16 * q + lr] -= acc[rr];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Solve X * L^T = P for the 64 rows of Xs in place, L = Lo (64x64 lower, unit-padded), right-looking:
 // four lanes per row keep the not-yet-solved right-hand side p[4t+q] in rotating registers; each
 // step scales one entry, broadcasts it over the quad (DPP) and updates the rest:
@@ -1041,7 +1232,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restri
             sub_acc64(S, acc, bs, bs, true);
         }
     }
-    if (!(dbg & 1)) potrf64_lds(S, Lo, colbuf, pvbuf, badflag, bs);      // starts and ends with a barrier
+    if (dbg & 8) potrf64_lds(S, Lo, colbuf, pvbuf, badflag, bs);         // previous column-per-barrier version
+    else if (!(dbg & 1)) { __syncthreads(); potrf64_blk(S, Lo, Ak, badflag, bs); }   // ends with a barrier
     else { __syncthreads(); for (int e = tid; e < NB * SP; e += NTHREADS) Lo[e] = S[e]; __syncthreads(); }
     const bool bad = (*badflag != 0);
     if (diag) {
@@ -1065,7 +1257,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restri
     __syncthreads();
     if (kprev >= 0 && !(dbg & 4)) sub_acc64(Xs, pacc, mi, bs, false);
     __syncthreads();
-    if (!(dbg & 2)) trsm64_lds(Xs, Lo, rinv);
+    if ((dbg & 8) || (dbg & 16)) { if (!(dbg & 2)) trsm64_lds(Xs, Lo, rinv); }   // previous scalar version
+    else if (!(dbg & 2)) trsm64_blk(Xs, Lo, Ak);
     __syncthreads();
     bp.from_lds(Xs, SP);
     bp.store(Pik, lda, mi, bs, false);
@@ -1367,6 +1560,9 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
             case 11: ACC_LAUNCH_G(1); break;
             case 12: ACC_LAUNCH_G(2); break;
             case 13: ACC_LAUNCH_G(3); break;
+            case 14: ACC_LAUNCH_G(4); break;
+            case 15: ACC_LAUNCH_G(8); break;
+            case 16: ACC_LAUNCH_G(7); break;
             case 0: ACC_LAUNCH_VAR(0); break;
             case 1: ACC_LAUNCH_VAR(1); break;
             case 2: ACC_LAUNCH_VAR(2); break;
@@ -1378,6 +1574,9 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
     ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 1>, T::G_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 2>, T::G_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 3>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 4>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 8>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 7>, T::G_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 1>, T::LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 2>, T::LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 3>, T::LDS_BYTES));
