@@ -262,7 +262,7 @@ extern "C" int accbpg_test_gemm(const double* A_dev, int64_t lda, const double* 
 
 extern "C" int accbpg_debug_chol_variant(accbpg_dopt* h, int bits) {
     if (!h) return ACCBPG_ERR_ARG;
-    h->chol_dbg = bits & 31;
+    h->chol_dbg = bits & 63;
     if (bits & 256) h->use_glds = false;      // bit 8: register-staged Gram / gradient kernels
     if (bits & 512) h->use_glds = true;
     return ACCBPG_OK;

@@ -791,7 +791,7 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
     return y;
 }
 
-// quad broadcast on DPP: every lane of a quad gets lane `src`'s value, no LDS round trip
+// quad broadcast on DPP: every lane of a quad gets lane `SRC`'s value, no LDS round trip
 template <int SRC>
 __device__ __forceinline__ double quad_bcast(double v) {
     constexpr int ctrl = SRC | (SRC << 2) | (SRC << 4) | (SRC << 6);
@@ -801,107 +801,46 @@ __device__ __forceinline__ double quad_bcast(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// Factor the 64x64 block image S (lower, identity-padded beyond bs) into Lo.
-// Thread (r = tid & 63, q = tid >> 6) keeps row r's entries of the columns 4t+q in registers; the
-// register file is rotated one place after every group of four columns, so the loop over groups is
-// a real loop (small body, stays in the instruction cache) with compile-time register indices.
-// Per column one barrier: the owner wave of column c+1 publishes it UNSCALED right after its last
-// update, the owner of its diagonal entry also publishes (1/sqrt, sqrt) of the pivot; after the
-// barrier every thread needs one multiply for l_rc and one FMA per register:
-//   a[r][cc] -= (l_rc / piv) * a[cc][c].
-// Finished columns and entries above the diagonal carry garbage that is never read back.
-__device__ __forceinline__ void potrf64_lds(const double* __restrict__ S, double* __restrict__ Lo,
-                                            double* __restrict__ colbuf /* 2 x 64 (+64 junk) */,
-                                            double* __restrict__ pvbuf /* 2 */, int* __restrict__ badflag,
-                                            int bs) {
-    const int tid = threadIdx.x;
-    const int r = tid & 63;
-    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
-    double a[NB / 4];
-    __syncthreads();
+// x L16^T = p for one row of 16 entries P[row][k0 .. k0+15] -> X[row][k0 .. k0+15], four lanes per row: lane q of the quad keeps
+// the entries of the columns 4t+q.  Per column one multiply, one quad broadcast and the updates of the
+// columns to the right; lt[c*16 + cc] = L16[cc][c] (zero above the diagonal), rv[c] = 1/L16[c][c].
+__device__ __forceinline__ void solve16_quad(const double* P, double* X, int row, int k0,
+                                             const double* __restrict__ lt, const double* __restrict__ rv) {
+    const int q = threadIdx.x & 3;
+    const double* prow = P + row * SP + k0;
+    double* xr = X + row * SP + k0;                               // may be the same image as P
+    double pr[4], xs[4];
 #pragma unroll
-    for (int t = 0; t < NB / 4; ++t) a[t] = S[r * SP + 4 * t + q];
-    if (q == 0) {
-        colbuf[r] = a[0];
-        if (r == 0) {
-            double d = a[0];
-            if (!(d > 0.0)) { *badflag = 1; d = 1.0; }
-            pvbuf[0] = rsqrt_newton(d);
-        }
+    for (int t = 0; t < 4; ++t) pr[t] = prow[4 * t + q];
+    // every factor entry this lane will need, fetched before the dependent chain starts (the stores of
+    // the results come after it: LDS stores in between would pin the loads behind them)
+    double lv[16][4], rvv[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        rvv[c] = rv[c];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (4 * t + 3 > c) lv[c][t] = lt[c * 16 + 4 * t + q];
     }
-    __syncthreads();
-    // The step body is branch-free (one basic block between barriers) so that the compiler can
-    // overlap the pivot chain -- LDS reads, two multiplies, one FMA, 1/sqrt by v_rsq_f64 + Newton,
-    // one 8-byte publish -- with the sixteen register updates: every lane computes the reciprocal
-    // square root of ITS candidate for the next pivot, and stores that are not the owner's go to a
-    // junk slot instead of being skipped.  The diagonal of L (a true square root) is off that chain:
-    // each row keeps its pivot value and takes the root after the loop.
-    double* junk = colbuf + 2 * NB;                               // NB doubles nobody relies on
-    double dsave = 1.0;
-    // `live` registers (columns still to the right) shrink by one per group of four columns; the
-    // loop is cut into four chunks with compile-time bounds 16/12/8/4 so finished registers cost
-    // neither LDS reads nor FMAs (the step is bound by its LDS instruction volume).
-    auto group = [&](int cg, auto live_tag) {
-        constexpr int LIVE = decltype(live_tag)::value;
+    auto column = [&](auto ctag) {
+        constexpr int c = decltype(ctag)::value;
+        constexpr int qc = c & 3, tc = c >> 2;
+        const double x = quad_bcast<qc>(pr[tc] * rvv[c]);
+        xs[tc] = (q == qc) ? x : xs[tc];
 #pragma unroll
-        for (int ci = 0; ci < 4; ++ci) {
-            const int c = 4 * cg + ci;
-            const int par = ci & 1;                               // c & 1
-            const double* col = colbuf + par * NB;
-            const double rp = pvbuf[par];
-            const double arc = col[r];
-            const double* colq = col + 4 * cg + q;
-            double cv[LIVE];
-#pragma unroll
-            for (int t = 0; t < LIVE; ++t) cv[t] = colq[4 * t];   // one batch of independent reads
-            const double lrc = arc * rp;                          // row c itself: d * 1/sqrt(d) ~ sqrt(d), fixed below
-            dsave = (r == c) ? arc : dsave;
-            const double w = lrc * rp;
-            // column c+1 lives in a[0] of wave ci+1, or (ci == 3) in a[1] of wave 0
-            const int qn = (ci + 1) & 3;
-            const int tn = (ci == 3) ? 1 : 0;
-            if constexpr (LIVE > 1) {
-                a[tn] = fma(-w, cv[tn], a[tn]);                   // heads the dependent chain
-            } else {
-                if (tn == 0) a[0] = fma(-w, cv[0], a[0]);
-            }
-            const double anext = (LIVE > 1 || tn == 0) ? a[(LIVE > 1) ? tn : 0] : 1.0;
-            const bool own_next = (q == qn);
-            {
-                double* dst = own_next ? (colbuf + (par ^ 1) * NB + r) : (junk + r);
-                *dst = anext;
-                const bool is_piv = own_next && (r == c + 1);
-                const bool nonpos = !(anext > 0.0);
-                const double rpn = rsqrt_newton(fmax(anext, 1e-300));
-                double* pdst = is_piv ? (pvbuf + (par ^ 1)) : (junk + (r & 31));
-                *pdst = rpn;
-                int* bdst = (is_piv && nonpos && c + 1 < bs) ? badflag : reinterpret_cast<int*>(junk + NB - 2);
-                *bdst = 1;
-            }
-            {
-                double* ldst = (q == ci) ? (Lo + r * SP + c) : (junk + 32 + (r & 15));
-                *ldst = (r >= c) ? lrc : 0.0;
-            }
-#pragma unroll
-            for (int t = 0; t < LIVE; ++t)
-                if (t != tn) a[t] = fma(-w, cv[t], a[t]);
-            __syncthreads();
-        }
-#pragma unroll
-        for (int t = 0; t + 1 < NB / 4; ++t) a[t] = a[t + 1];
-        a[NB / 4 - 1] = 0.0;
+        for (int t = 0; t < 4; ++t)
+            if (4 * t + 3 > c) pr[t] = fma(-x, lv[c][t], pr[t]);      // (a finished entry may take junk)
     };
-#pragma unroll 1
-    for (int cg = 0; cg < 4; ++cg) group(cg, std::integral_constant<int, 16>{});
-#pragma unroll 1
-    for (int cg = 4; cg < 8; ++cg) group(cg, std::integral_constant<int, 12>{});
-#pragma unroll 1
-    for (int cg = 8; cg < 12; ++cg) group(cg, std::integral_constant<int, 8>{});
-#pragma unroll 1
-    for (int cg = 12; cg < 16; ++cg) group(cg, std::integral_constant<int, 4>{});
-    // diagonal: L[r][r] = sqrt(pivot value of row r) (rows >= bs hold the identity padding: 1)
-    if (q == 0) Lo[r * SP + r] = sqrt(dsave);
-    __syncthreads();
+    column(std::integral_constant<int, 0>{});  column(std::integral_constant<int, 1>{});
+    column(std::integral_constant<int, 2>{});  column(std::integral_constant<int, 3>{});
+    column(std::integral_constant<int, 4>{});  column(std::integral_constant<int, 5>{});
+    column(std::integral_constant<int, 6>{});  column(std::integral_constant<int, 7>{});
+    column(std::integral_constant<int, 8>{});  column(std::integral_constant<int, 9>{});
+    column(std::integral_constant<int, 10>{}); column(std::integral_constant<int, 11>{});
+    column(std::integral_constant<int, 12>{}); column(std::integral_constant<int, 13>{});
+    column(std::integral_constant<int, 14>{}); column(std::integral_constant<int, 15>{});
+#pragma unroll
+    for (int t = 0; t < 4; ++t) xr[4 * t + q] = xs[t];
 }
 
 // value of lane `SRC` of each 16-lane row, in every lane of that row (DPP row_newbcast, no SGPR round trip)
@@ -913,40 +852,58 @@ __device__ __forceinline__ double row_bcast(double v) {
     hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
-template <int J, int C>
-__device__ __forceinline__ void potrf16_rest(double (&a)[16], double l) {
-    if constexpr (C < 16) {
-        a[C] = fma(-l, row_bcast<C>(l), a[C]);
-        potrf16_rest<J, C + 1>(a, l);
-    }
+// two rank-1 updates of step J (columns C, C+1), skipped past column 15
+template <int C>
+__device__ __forceinline__ void potrf16_upd2(double (&a)[16], double l) {
+    if constexpr (C < 16) a[C] = fma(-l, row_bcast<C>(l), a[C]);
+    if constexpr (C + 1 < 16) a[C + 1] = fma(-l, row_bcast<C + 1>(l), a[C + 1]);
+    __builtin_amdgcn_sched_barrier(0);
 }
+// Step J of the 16x16 factorisation: `l` holds column J of the factor (entry of this lane's row).  The
+// dependent chain of the NEXT column -- its pivot, 1/sqrt, the scaling of the column -- bounds the step
+// (about 18 cycles per dependent fp64 operation), so it is kept as short as the arithmetic allows: the
+// scaling factor is v_rsq_f64 refined by ONE Newton step (2^-26 -> about 2^-51 relative; it only scales
+// the column, the diagonal entry and the log-determinant use a correctly rounded sqrt of the pivot), and
+// this step's independent rank-1 updates are dealt out between its links.
 template <int J>
-__device__ __forceinline__ void potrf16_step(double (&a)[16], int r, int k0, int bs, double& dsv, double& myrs,
-                                             double& minp) {
-    const double piv = row_bcast<J>(a[J]);
-    minp = fmin(minp, (k0 + J < bs) ? piv : 1.0);
-    const double rs = rsqrt_newton(piv);     // a non-positive pivot turns the block into NaNs; minp reports it
-    const double l = a[J] * rs;
-    dsv = (r == J) ? piv : dsv;
-    myrs = (r == J) ? rs : myrs;
+__device__ __forceinline__ void potrf16_step(double (&a)[16], double& l, int r, int k0, int bs, double& dsv,
+                                             double& myrs, double& minp) {
     a[J] = l;
     if constexpr (J + 1 < 16) {
-        // the entry that becomes the next pivot first
-        a[J + 1] = fma(-l, row_bcast<J + 1>(l), a[J + 1]);
+        a[J + 1] = fma(-l, row_bcast<J + 1>(l), a[J + 1]);           // becomes the next pivot
+        const double piv = row_bcast<J + 1>(a[J + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        double y = __builtin_amdgcn_rsq(piv);                        // (a non-positive pivot spreads NaNs; minp reports it)
+        const double h = -0.5 * piv;
+        minp = fmin(minp, (k0 + J + 1 < bs) ? piv : 1.0);
+        dsv = (r == J + 1) ? piv : dsv;
+        potrf16_upd2<J + 2>(a, l);
+        potrf16_upd2<J + 4>(a, l);
+        const double t = h * y;
+        potrf16_upd2<J + 6>(a, l);
+        potrf16_upd2<J + 8>(a, l);
+        const double u = fma(t, y, 1.5);
+        potrf16_upd2<J + 10>(a, l);
+        potrf16_upd2<J + 12>(a, l);
+        y = y * u;                                                   // ONE Newton step, see below
+        potrf16_upd2<J + 14>(a, l);
+        myrs = (r == J + 1) ? y : myrs;
+        l = a[J + 1] * y;
+        __builtin_amdgcn_sched_barrier(0);
     }
-    potrf16_rest<J, J + 2>(a, l);
 }
 // Blocked factorisation of the 64x64 block image S (lower, identity-padded beyond bs) into Lo, in four
 // panels of 16 columns:
 //   A  one wavefront factors the 16x16 diagonal block with a row per lane in registers -- the pivot and
-//      the column entries travel by v_readlane, no LDS round trip and no barrier inside the 16 steps;
-//   B  the rows below solve against it, a thread per row, the 16x16 factor read as LDS broadcasts;
+//      the column entries travel by DPP row broadcasts, no LDS round trip and no barrier in the 16 steps;
+//   B  the rows below solve against it, four lanes per row (solve16_quad);
 //   C  the trailing blocks take their rank-16 update on the MFMA pipe.
 // Three barriers per panel instead of one per column; the serial chain is 64 register-resident steps.
 // `tbuf`: 4 * POTRF_TB doubles of scratch.  Lo gets the lower triangle, zeros above it.
 constexpr int POTRF_TB = 16 * 16 + 16;
 __device__ __forceinline__ void potrf64_blk(double* __restrict__ S, double* __restrict__ Lo,
-                                            double* __restrict__ tbuf, int* __restrict__ badflag, int bs) {
+                                            double* __restrict__ tbuf, int* __restrict__ badflag, int bs,
+                                            int dbg = 0) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // per panel: lt[c*16 + cc] = L16[cc][c] (column c of the panel's diagonal factor), rv[c] = 1 / L16[c][c];
@@ -964,28 +921,37 @@ __device__ __forceinline__ void potrf64_blk(double* __restrict__ S, double* __re
         double* lt = tbuf + pnl * POTRF_TB;
         double* rv = lt + 256;
         // ---- A: 16x16 diagonal block on wavefront 0 (every lane l works on row l & 15)
-        if (wave == 0) {
+        if (wave == 0 && !(dbg & 32)) {
             const int r = lane & 15;
             double a[16];
 #pragma unroll
             for (int c = 0; c < 16; ++c) a[c] = S[(k0 + r) * SP + k0 + c];
             double dsv = 1.0, myrs = 1.0, minp = 1.0;
-            potrf16_step<0>(a, r, k0, bs, dsv, myrs, minp);
-            potrf16_step<1>(a, r, k0, bs, dsv, myrs, minp);
-            potrf16_step<2>(a, r, k0, bs, dsv, myrs, minp);
-            potrf16_step<3>(a, r, k0, bs, dsv, myrs, minp);
-            potrf16_step<4>(a, r, k0, bs, dsv, myrs, minp);
-            potrf16_step<5>(a, r, k0, bs, dsv, myrs, minp);
-            potrf16_step<6>(a, r, k0, bs, dsv, myrs, minp);
-            potrf16_step<7>(a, r, k0, bs, dsv, myrs, minp);
-            potrf16_step<8>(a, r, k0, bs, dsv, myrs, minp);
-            potrf16_step<9>(a, r, k0, bs, dsv, myrs, minp);
-            potrf16_step<10>(a, r, k0, bs, dsv, myrs, minp);
-            potrf16_step<11>(a, r, k0, bs, dsv, myrs, minp);
-            potrf16_step<12>(a, r, k0, bs, dsv, myrs, minp);
-            potrf16_step<13>(a, r, k0, bs, dsv, myrs, minp);
-            potrf16_step<14>(a, r, k0, bs, dsv, myrs, minp);
-            potrf16_step<15>(a, r, k0, bs, dsv, myrs, minp);
+            double l;
+            {
+                const double piv = row_bcast<0>(a[0]);
+                minp = (k0 < bs) ? piv : 1.0;
+                const double rs = rsqrt_newton(piv);
+                dsv = (r == 0) ? piv : dsv;
+                myrs = (r == 0) ? rs : myrs;
+                l = a[0] * rs;
+            }
+            potrf16_step<0>(a, l, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<1>(a, l, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<2>(a, l, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<3>(a, l, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<4>(a, l, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<5>(a, l, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<6>(a, l, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<7>(a, l, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<8>(a, l, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<9>(a, l, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<10>(a, l, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<11>(a, l, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<12>(a, l, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<13>(a, l, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<14>(a, l, r, k0, bs, dsv, myrs, minp);
+            potrf16_step<15>(a, l, r, k0, bs, dsv, myrs, minp);
             const bool bad = !(minp > 0.0);
             const double dg = sqrt(dsv);
             if (lane < 16) {
@@ -1001,22 +967,11 @@ __device__ __forceinline__ void potrf64_blk(double* __restrict__ S, double* __re
         }
         __syncthreads();
         if (pnl == NB / 16 - 1) break;
-        // ---- B: rows below the diagonal block: x L16^T = p, one thread per row
+        // ---- B: rows below the diagonal block: x L16^T = p, four lanes per row
         const int nrows = NB - k0 - 16;
-        if (tid < nrows) {
-            const int row = k0 + 16 + tid;
-            double pr[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) pr[c] = S[row * SP + k0 + c];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const double xc = pr[c] * rv[c];
-                pr[c] = xc;
-#pragma unroll
-                for (int cc = c + 1; cc < 16; ++cc) pr[cc] = fma(-xc, lt[c * 16 + cc], pr[cc]);
-            }
-#pragma unroll
-            for (int c = 0; c < 16; ++c) Lo[row * SP + k0 + c] = pr[c];
+        if (tid < 4 * nrows && !(dbg & 8)) {
+            const int row = k0 + 16 + (tid >> 2);
+            solve16_quad(S, Lo, row, k0, lt, rv);
         }
         __syncthreads();
         // ---- C: trailing update S(bi,bj) -= X_bi X_bj^T on the MFMA pipe, 16x16 blocks bi >= bj > pnl
@@ -1024,7 +979,7 @@ __device__ __forceinline__ void potrf64_blk(double* __restrict__ S, double* __re
             const int nb = NB / 16 - 1 - pnl;                      // remaining 16-blocks per dimension
             const int nblk = nb * (nb + 1) / 2;
             const int lr = lane & 15, lq = lane >> 4;
-            for (int b = wave; b < nblk; b += NTHREADS / 64) {
+            for (int b = wave; b < nblk && !(dbg & 16); b += NTHREADS / 64) {
                 int bi = 0;
                 while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
                 const int bj = b - bi * (bi + 1) / 2;
@@ -1056,20 +1011,7 @@ __device__ __forceinline__ void trsm64_blk(double* __restrict__ Xs, const double
         const int k0 = 16 * pnl;
         const double* lt = tbuf + pnl * POTRF_TB;
         const double* rv = lt + 256;
-        if (wave == 0) {
-            double pr[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) pr[c] = Xs[lane * SP + k0 + c];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const double xc = pr[c] * rv[c];
-                pr[c] = xc;
-#pragma unroll
-                for (int cc = c + 1; cc < 16; ++cc) pr[cc] = fma(-xc, lt[c * 16 + cc], pr[cc]);
-            }
-#pragma unroll
-            for (int c = 0; c < 16; ++c) Xs[lane * SP + k0 + c] = pr[c];
-        }
+        solve16_quad(Xs, Xs, tid >> 2, k0, lt, rv);
         if (pnl == NB / 16 - 1) break;
         __syncthreads();
         {
@@ -1093,59 +1035,6 @@ __device__ __forceinline__ void trsm64_blk(double* __restrict__ Xs, const double
     }
 }
 
-// Solve X * L^T = P for the 64 rows of Xs in place, L = Lo (64x64 lower, unit-padded), right-looking:
-// four lanes per row keep the not-yet-solved right-hand side p[4t+q] in rotating registers; each
-// step scales one entry, broadcasts it over the quad (DPP) and updates the rest:
-//   x_c = p_c / L[c][c];  p_cc -= x_c * L[cc][c].   No barrier inside.
-__device__ __forceinline__ void trsm64_lds(double* __restrict__ Xs, const double* __restrict__ Lo,
-                                           const double* __restrict__ rinv) {
-    const int tid = threadIdx.x;
-    const int row = tid >> 2, q = tid & 3;
-    double p[NB / 4];
-#pragma unroll
-    for (int t = 0; t < NB / 4; ++t) p[t] = Xs[row * SP + 4 * t + q];
-    auto group = [&](int cg, auto live_tag) {
-        constexpr int LIVE = decltype(live_tag)::value;         // registers whose column is <= 63
-        // rows (4cg+q+4t) of L for the live registers (wrapped into 0..63 where a chunk's bound still
-        // covers a register that has already moved past column 63)
-        const double* lrow[LIVE];
-#pragma unroll
-        for (int t = 0; t < LIVE; ++t) lrow[t] = Lo + ((4 * cg + q + 4 * t) & (NB - 1)) * SP + 4 * cg;
-        double xc[4];
-#pragma unroll
-        for (int ci = 0; ci < 4; ++ci) {
-            const int c = 4 * cg + ci;
-            double lv[LIVE];
-#pragma unroll
-            for (int t = 0; t < LIVE; ++t) lv[t] = lrow[t][ci];   // independent of the solve chain
-            const double mine = p[0] * rinv[c];
-            double x;
-            if (ci == 0) x = quad_bcast<0>(mine);
-            else if (ci == 1) x = quad_bcast<1>(mine);
-            else if (ci == 2) x = quad_bcast<2>(mine);
-            else x = quad_bcast<3>(mine);
-            xc[ci] = x;
-#pragma unroll
-            for (int t = 0; t < LIVE; ++t) p[t] = fma(-x, lv[t], p[t]);
-        }
-        if (q == 0) Xs[row * SP + 4 * cg + 0] = xc[0];
-        if (q == 1) Xs[row * SP + 4 * cg + 1] = xc[1];
-        if (q == 2) Xs[row * SP + 4 * cg + 2] = xc[2];
-        if (q == 3) Xs[row * SP + 4 * cg + 3] = xc[3];
-#pragma unroll
-        for (int t = 0; t + 1 < NB / 4; ++t) p[t] = p[t + 1];
-        p[NB / 4 - 1] = 0.0;
-    };
-#pragma unroll 1
-    for (int cg = 0; cg < 4; ++cg) group(cg, std::integral_constant<int, 16>{});
-#pragma unroll 1
-    for (int cg = 4; cg < 8; ++cg) group(cg, std::integral_constant<int, 12>{});
-#pragma unroll 1
-    for (int cg = 8; cg < 12; ++cg) group(cg, std::integral_constant<int, 8>{});
-#pragma unroll 1
-    for (int cg = 12; cg < 16; ++cg) group(cg, std::integral_constant<int, 4>{});
-}
-
 __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restrict__ A, int64_t lda, int64_t m,
                                                                int kprev, int T, double* __restrict__ logdet,
                                                                int* __restrict__ flags, int dbg) {
@@ -1154,11 +1043,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restri
     double* Bk = Ak + NB * SQ;              // 64 x SQ : L(kc,kprev) (or L(j,kprev)) operand image
     double* S = Bk + NB * SQ;               // 64 x SP : diagonal block image, later the panel block
     double* Lo = S + NB * SP;               // 64 x SP (+ pad rows read by the solve): factor
-    double* rinv = Lo + NB * SP;            // NB, followed by NB of zero pad (rows 64.. of Lo reads)
-    double* colbuf = rinv + 2 * NB;         // 2 x NB + NB pad
-    double* pvbuf = colbuf + 3 * NB;        // 4 (+ flag)
-    int* badflag = reinterpret_cast<int*>(pvbuf + 8);
-    double* red = pvbuf + 16;
+    double* misc = Lo + NB * SP;            // small scratch behind the images
+    int* badflag = reinterpret_cast<int*>(misc);
+    double* red = misc + 8;
     const int tid = threadIdx.x;
     const int kc = kprev + 1;
     const int npanel = T - kc;
@@ -1218,8 +1105,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restri
             S[r * SP + c + 1] = (in && c + 1 <= r && c + 1 < bs) ? bd.v[p].y : ((r == c + 1) ? 1.0 : 0.0);
         }
     }
-    for (int e = tid; e < 2 * NB; e += NTHREADS) rinv[e] = 0.0;
-    for (int e = tid; e < 3 * NB; e += NTHREADS) colbuf[e] = 0.0;
     if (tid == 0) *badflag = 0;
     acc64_t pacc;
     if (kprev >= 0) {
@@ -1232,8 +1117,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restri
             sub_acc64(S, acc, bs, bs, true);
         }
     }
-    if (dbg & 8) potrf64_lds(S, Lo, colbuf, pvbuf, badflag, bs);         // previous column-per-barrier version
-    else if (!(dbg & 1)) { __syncthreads(); potrf64_blk(S, Lo, Ak, badflag, bs); }   // ends with a barrier
+    __syncthreads();
+    if (!(dbg & 1)) potrf64_blk(S, Lo, Ak, badflag, bs, dbg);            // ends with a barrier
     else { __syncthreads(); for (int e = tid; e < NB * SP; e += NTHREADS) Lo[e] = S[e]; __syncthreads(); }
     const bool bad = (*badflag != 0);
     if (diag) {
@@ -1253,12 +1138,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restri
     // panel block: P = A(i,kc) - L(i,kprev) L(kc,kprev)^T, then X L^T = P
     double* Xs = S;                                      // the diagonal image is dead after the factorisation
     bp.to_lds(Xs, SP);
-    if (tid < NB) rinv[tid] = (tid < bs) ? 1.0 / Lo[tid * SP + tid] : 0.0;
     __syncthreads();
     if (kprev >= 0 && !(dbg & 4)) sub_acc64(Xs, pacc, mi, bs, false);
     __syncthreads();
-    if ((dbg & 8) || (dbg & 16)) { if (!(dbg & 2)) trsm64_lds(Xs, Lo, rinv); }   // previous scalar version
-    else if (!(dbg & 2)) trsm64_blk(Xs, Lo, Ak);
+    if (!(dbg & 2)) trsm64_blk(Xs, Lo, Ak);
     __syncthreads();
     bp.from_lds(Xs, SP);
     bp.store(Pik, lda, mi, bs, false);
