@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--linear-gram", action="store_true",
                     help="measure with Gram-matrix reuse through linearity switched on (extension); the "
                          "default run reports it separately as linear_gram_variant")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="skip the overlap / linear-gram variant segments (profiling runs: the kernel trace then "
+                         "holds the headline region only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     return ap.parse_args()
@@ -268,7 +271,8 @@ def main():
 
     # same workload once more with F[k] = f(x) overlapped with the gradient evaluation (two streams)
     ovl_variant = None
-    if (not args.linear_gram) and (not shard) and ipg == 1 and args.workload in ("abpg_gain", "abpg"):
+    if (not args.no_variants) and (not args.linear_gram) and (not shard) and ipg == 1 \
+            and args.workload in ("abpg_gain", "abpg"):
         f.overlap_values(True)
         if args.workload == "abpg_gain":
             gen3 = alg.ABPG_gain_steps(f, h, 1.0, x0, 2, total + 1, verbose=False)
@@ -294,7 +298,8 @@ def main():
 
     # same workload once more with Gram-matrix reuse through linearity (extension, reported apart)
     lin_variant = None
-    if (not args.linear_gram) and (not shard) and ipg == 1 and args.workload in ("abpg_gain", "abpg"):
+    if (not args.no_variants) and (not args.linear_gram) and (not shard) and ipg == 1 \
+            and args.workload in ("abpg_gain", "abpg"):
         f.linear_gram(True)
         if args.workload == "abpg_gain":
             gen2 = alg.ABPG_gain_steps(f, h, 1.0, x0, 2, total + 1, verbose=False)

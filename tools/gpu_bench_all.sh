@@ -22,13 +22,13 @@ run cfg1 "--m 80 --n 200 --workload bpg --steps 500 --warmup 20 --no-cpu-baselin
 run poisson "--workload poisson_abpg --steps 50 --warmup 5"
 run cfg4x8 "--m 512 --n 8192 --workload abpg --steps 100 --warmup 10 --no-cpu-baseline --instances-per-gpu 8"
 export TMPDIR=/tmp; cd /tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_main -- python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $REPO/gpurun_out/prof_main.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_main -- python3 $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-variants > $REPO/gpurun_out/prof_main.log 2>&1
 echo "rocprof main rc=$?"
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $REPO/gpurun_out/pmc_fetch -- python3 $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $REPO/gpurun_out/pmc_fetch.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $REPO/gpurun_out/pmc_fetch -- python3 $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-variants > $REPO/gpurun_out/pmc_fetch.log 2>&1
 echo "pmc fetch rc=$?"
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $REPO/gpurun_out/pmc_write -- python3 $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $REPO/gpurun_out/pmc_write.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $REPO/gpurun_out/pmc_write -- python3 $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-variants > $REPO/gpurun_out/pmc_write.log 2>&1
 echo "pmc write rc=$?"
-timeout -k 10 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $REPO/gpurun_out/pmc_sq -- python3 $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $REPO/gpurun_out/pmc_sq.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $REPO/gpurun_out/pmc_sq -- python3 $REPO/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-variants > $REPO/gpurun_out/pmc_sq.log 2>&1
 echo "pmc sq rc=$?"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_fw -- python3 $REPO/bench.py --workload fw --steps 100 --warmup 5 --no-cpu-baseline > $REPO/gpurun_out/prof_fw.log 2>&1
 echo "rocprof fw rc=$?"

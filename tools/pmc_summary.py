@@ -2,7 +2,13 @@
 import csv, glob, os, sys, collections
 root = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for path in sorted(glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
+# one pass = one directory; gpurun_out accumulates over calls, so only the newest file of each pass counts
+paths = []
+for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if files:
+        paths.append(max(files, key=os.path.getmtime))
+for path in paths:
     with open(path) as fh:
         for row in csv.DictReader(fh):
             name = row.get("Kernel_Name", "")[:60]
