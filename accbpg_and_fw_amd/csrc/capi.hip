@@ -83,7 +83,7 @@ extern "C" int accbpg_dopt_create(const double* V_dev, int64_t m, int64_t n, int
 
 extern "C" int accbpg_dopt_destroy(accbpg_dopt* h) {
     if (!h) return ACCBPG_OK;
-    hipFree(h->Lbuf); hipFree(h->Wbuf); hipFree(h->Tbuf); hipFree(h->slabs); hipFree(h->tiles);
+    hipFree(h->Lbuf); hipFree(h->Wbuf); hipFree(h->Tbuf); hipFree(h->slabs); hipFree(h->tiles); hipFree(h->wg_ranges); hipFree(h->gram_cstart); hipFree(h->gram_contrib);
     hipFree(h->dscal); hipFree(h->dflag); hipFree(h->vws); hipFree(h->xbuf); hipFree(h->ops); hipFree(h->chol_op);
     hipFree(h->fw_x); hipFree(h->fw_w); hipFree(h->fw_H); hipFree(h->fw_hv);
     if (h->hpin) hipHostFree(h->hpin);

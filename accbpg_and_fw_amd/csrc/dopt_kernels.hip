@@ -23,6 +23,7 @@ struct GramSeg {
     int64_t row0, col0, kb, ke;
     bool dual, whole;
 };
+constexpr int GRAM_RMAX = 4;    // unit ranges a workgroup can own (wg_ranges[w][r] = {first, end})
 template <class T>
 __device__ __forceinline__ GramSeg gram_segment(const TileRC* __restrict__ tiles, int64_t kiters, int64_t it,
                                                 int64_t it1) {
@@ -58,16 +59,15 @@ __device__ __forceinline__ GramSeg gram_segment(const TileRC* __restrict__ tiles
 template <class T, int VAR = 0>
 __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_kernel(
     const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n, const double* __restrict__ x,
-    const TileRC* __restrict__ tiles, int ntiles, int64_t kiters, int64_t per, int nslot,
+    const TileRC* __restrict__ tiles, const int64_t* __restrict__ wg_ranges, int64_t kiters, int nslot,
     double* __restrict__ slabs,
     double* __restrict__ G, int64_t ldg, bool vec_ok) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int64_t total = (int64_t)ntiles * kiters;
-    const int64_t it0 = min((int64_t)blockIdx.x * per, total);
-    const int64_t it1 = min(it0 + per, total);
     T t;
-    int64_t it = it0;
     int seg = 0;
+    for (int rg = 0; rg < GRAM_RMAX; ++rg) {
+    int64_t it = wg_ranges[((int64_t)blockIdx.x * GRAM_RMAX + rg) * 2];
+    const int64_t it1 = wg_ranges[((int64_t)blockIdx.x * GRAM_RMAX + rg) * 2 + 1];
     while (it < it1) {
         const GramSeg sg = gram_segment<T>(tiles, kiters, it, it1);   // never dual: pairs exist on the glds path only
         const int64_t kb = sg.kb, ke = sg.ke, row0 = sg.row0, col0 = sg.col0;
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_kernel(
         it += ke - kb;
         ++seg;
     }
+    }
 }
 
 // Direct-to-LDS version of the Gram kernel for interior tiles (same stream-K decomposition and
@@ -149,17 +150,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_kernel(
 template <class T, int GV = 0, int NSTAGE = 3, int WPS = 1>
 __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
     const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n, const double* __restrict__ x,
-    const TileRC* __restrict__ tiles, int ntiles, int64_t kiters, int64_t per, int nslot,
+    const TileRC* __restrict__ tiles, const int64_t* __restrict__ wg_ranges, int64_t kiters, int nslot,
     double* __restrict__ slabs,
     double* __restrict__ G, int64_t ldg) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NLD = T::G_NA + T::G_NB + 1;                  // loads per wave per stage
-    const int64_t total = (int64_t)ntiles * kiters;
-    const int64_t it0 = min((int64_t)blockIdx.x * per, total);
-    const int64_t it1 = min(it0 + per, total);
     T t;
-    int64_t it = it0;
     int seg = 0;
+    for (int rg = 0; rg < GRAM_RMAX; ++rg) {
+    int64_t it = wg_ranges[((int64_t)blockIdx.x * GRAM_RMAX + rg) * 2];
+    const int64_t it1 = wg_ranges[((int64_t)blockIdx.x * GRAM_RMAX + rg) * 2 + 1];
     while (it < it1) {
         const GramSeg sg = gram_segment<T>(tiles, kiters, it, it1);
         const int64_t kb = sg.kb, ke = sg.ke, row0 = sg.row0, col0 = sg.col0;
@@ -326,6 +326,7 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
         it += ke - kb;
         ++seg;
     }
+    }
 }
 
 // grid = ntiles * 2 * T::MI * FIX_PJ: workgroup (entry, half, part, jq) sums column-fragment group jq of
@@ -334,8 +335,8 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
 constexpr int FIX_PJ = 4;
 template <class T>
 __global__ __launch_bounds__(NTHREADS, 2) void gram_fixup_kernel(
-    const TileRC* __restrict__ tiles, int ntiles, int64_t kiters, int64_t per, int nslot,
-    const double* __restrict__ slabs, double* __restrict__ G, int64_t ldg, int64_t m) {
+    const TileRC* __restrict__ tiles, const int32_t* __restrict__ cstart, const int32_t* __restrict__ contrib,
+    int nslot, const double* __restrict__ slabs, double* __restrict__ G, int64_t ldg, int64_t m) {
     constexpr int JW = (T::NI + FIX_PJ - 1) / FIX_PJ;
     const int jq = blockIdx.x % FIX_PJ;
     const int b = blockIdx.x / FIX_PJ;
@@ -344,14 +345,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gram_fixup_kernel(
     if (j0 >= T::NI) return;
     const TileRC tr = tiles[e];
     const bool dual = tr.d1 >= 0;
-    if (!dual && hs == 1) return;
     if (dual && part >= T::MI / 2) return;                  // rows i + MI/2 hold the second K half of rows i
-    const int64_t ulen = dual ? (kiters >> 1) : kiters;
-    const int64_t u0 = (int64_t)e * kiters + (hs ? ulen : 0), u1 = u0 + ulen - 1;
-    const int64_t w0 = u0 / per, w1 = u1 / per;
-    // both ends of an ordinary tile inside one workgroup's range: that workgroup ran it as one whole
-    // segment and stored it directly (dual tiles always leave slabs)
-    if (w0 == w1 && !dual) return;
+    // contributors of this tile (entry e, half hs): (workgroup, slot) pairs in k order; none when one
+    // workgroup ran the whole tile and stored it directly
+    const int c0 = cstart[2 * e + hs], c1 = cstart[2 * e + hs + 1];
+    if (c0 == c1) return;
     int64_t row0 = (int64_t)tr.rb * T::BM, col0 = (int64_t)tr.cb * T::BN;
     if (dual) row0 = col0 = (int64_t)(hs ? tr.d2 : tr.d1) * (T::BM / 2);
     // column fragments entirely above the diagonal are never stored
@@ -363,17 +361,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gram_fixup_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) a[jj][r] = 0.0;
     const int tid = threadIdx.x;
-    const int64_t total = (int64_t)ntiles * kiters;
-    for (int64_t w = w0; w <= w1; ++w) {
-        // slot = ordinal of this tile among the segments of workgroup w (replay of its walk)
-        int64_t it = w * per;
-        const int64_t it1 = min(it + per, total);
-        int slot = 0;
-        while (it < u0) {
-            const GramSeg sg = gram_segment<T>(tiles, kiters, it, it1);
-            it += sg.ke - sg.kb;
-            ++slot;
-        }
+    for (int c = c0; c < c1; ++c) {
+        const int64_t w = contrib[2 * c];
+        const int slot = contrib[2 * c + 1];
         const double* sl = slabs + (w * nslot + slot) * T::SLAB_DOUBLES;
 #pragma unroll
         for (int jj = 0; jj < JW; ++jj) {
@@ -1270,11 +1260,67 @@ int build_plans(accbpg_dopt* h) {
     int grid = (h->big && !h->gram_mid) ? h->num_cu : 2 * h->num_cu;
     if (grid > total) grid = (int)total;
     if (grid < h->ntiles && total / h->ntiles < 8) grid = h->ntiles;   // tiny K: one tile per workgroup
-    h->gram_per = 0;
     int64_t per = (total + grid - 1) / grid;
     grid = (int)((total + per - 1) / per);
     h->gram_grid = grid;
     h->gram_per = (int)per;
+    const int64_t kit = h->kiters;
+    // ---- unit ranges per workgroup.
+    // Plain stream-K hands workgroup w the contiguous range [w*per, (w+1)*per).  When a tile holds several
+    // whole ranges (q = kiters / per >= 1, remainder rem > 0) the ranges are instead ALIGNED to the
+    // tiles: every tile is cut at 0, per, .., q*per, so that all workgroups of "class" j start at k-step
+    // j*per of their tile and stream the same columns of V at the same time; the q*ntiles body pieces
+    // are dealt to the XCDs (workgroup id mod 8, round-robin placement -- speed only, never correctness)
+    // 32 at a time in an order in which 32 consecutive tiles form a compact block (few distinct row and
+    // column panels -> shared through that XCD's L2), and the remainders [q*per, kiters) are walked by
+    // the last workgroups as one contiguous stream.
+    std::vector<int64_t> ranges((size_t)grid * GRAM_RMAX * 2, 0);
+    const int64_t q = kit / per, rem = kit % per;
+    // (a tail workgroup crosses at most per/rem + 2 remainders)
+    const bool aligned = h->big && !h->gram_mid && q >= 1 && rem > 0 && (int64_t)h->ntiles * q < grid &&
+                         per / rem + 2 <= GRAM_RMAX;
+    if (aligned) {
+        // compact order of the entries: 4 x 8 blocks of tiles
+        std::stable_sort(tl.begin(), tl.end(), [](const TileRC& a, const TileRC& b) {
+            const int ka[4] = {a.rb / 4, a.cb / 8, a.rb, a.cb}, kb[4] = {b.rb / 4, b.cb / 8, b.rb, b.cb};
+            for (int i = 0; i < 4; ++i)
+                if (ka[i] != kb[i]) return ka[i] < kb[i];
+            return false;
+        });
+        const int nbody = (int)(h->ntiles * q);
+        const int px = (grid % 8 == 0) ? grid / 8 : 0;          // workgroups per XCD
+        auto wg_of = [&](int i) { return px ? (i / px) + 8 * (i % px) : i; };
+        int idx = 0;
+        for (int64_t j = 0; j < q; ++j)
+            for (int e = 0; e < h->ntiles; ++e, ++idx) {
+                const int w = wg_of(idx);
+                ranges[((size_t)w * GRAM_RMAX) * 2] = (int64_t)e * kit + j * per;
+                ranges[((size_t)w * GRAM_RMAX) * 2 + 1] = (int64_t)e * kit + (j + 1) * per;
+            }
+        // remainders: tail-workgroup t covers the concatenated tails' units [t*per, (t+1)*per)
+        const int64_t tail_total = (int64_t)h->ntiles * rem;
+        for (int t = 0; nbody + t < grid; ++t) {
+            const int w = wg_of(nbody + t);
+            int64_t u = (int64_t)t * per;
+            const int64_t u1 = std::min(u + per, tail_total);
+            int r = 0;
+            while (u < u1) {
+                const int64_t e = u / rem, off = u - e * rem;
+                const int64_t len = std::min(rem - off, u1 - u);
+                if (r >= GRAM_RMAX) return ACCBPG_ERR_ARG;      // cannot happen: per / rem + 2 <= GRAM_RMAX
+                ranges[((size_t)w * GRAM_RMAX + r) * 2] = e * kit + q * per + off;
+                ranges[((size_t)w * GRAM_RMAX + r) * 2 + 1] = e * kit + q * per + off + len;
+                ++r;
+                u += len;
+            }
+        }
+    }
+    if (!aligned) {
+        for (int w = 0; w < grid; ++w) {
+            ranges[((size_t)w * GRAM_RMAX) * 2] = std::min((int64_t)w * per, total);
+            ranges[((size_t)w * GRAM_RMAX) * 2 + 1] = std::min((int64_t)(w + 1) * per, total);
+        }
+    }
     // XCD-aware order.  Workgroups whose ranges start a whole number of tiles apart run the same
     // k-step at the same time; with `per` steps per workgroup those are workgroups dw = kiters/g apart
     // (g = gcd(per, kiters)), D = per/g tiles apart, and when dw is a multiple of 8 they share an XCD
@@ -1286,7 +1332,7 @@ int build_plans(accbpg_dopt* h) {
         const int64_t g = gcd64(per, h->kiters);
         const int64_t D = per / g, dw = h->kiters / g;
         const int nt = (int)tl.size();
-        if (h->big && D > 1 && D < nt && nt % D == 0 && dw % 8 == 0) {
+        if (!aligned && h->big && D > 1 && D < nt && nt % D == 0 && dw % 8 == 0) {
             const int gs = (int)(nt / D);
             // sequence in which consecutive runs are compact: row-block pairs, then 4 column blocks at a time
             std::vector<TileRC> seq;
@@ -1317,23 +1363,46 @@ int build_plans(accbpg_dopt* h) {
     }
     ACC_HIP(hipMalloc(&h->tiles, sizeof(TileRC) * tl.size()));
     ACC_HIP(hipMemcpy(h->tiles, tl.data(), sizeof(TileRC) * tl.size(), hipMemcpyHostToDevice));
-    // slab slots per workgroup = the most segments any workgroup walks through
+    // ---- replay every workgroup's walk (the device splits a range at tile and dual-half boundaries the
+    // same way): slab slot of each segment = its ordinal in the walk; contributors of each tile in k order
     {
+        struct Contrib { int64_t kb; int w, slot; };
+        std::vector<std::vector<Contrib>> cl((size_t)h->ntiles * 2);
+        const int64_t half = kit / 2;
         int nslot = 1;
-        const int64_t half = h->kiters / 2;
         for (int w = 0; w < grid; ++w) {
-            int64_t it = (int64_t)w * per;
-            const int64_t it1 = std::min(it + per, total);
-            int segs = 0;
-            while (it < it1) {
-                const int64_t e = it / h->kiters, off = it - e * h->kiters;
-                const int64_t end = (tl[(size_t)e].d1 < 0) ? h->kiters : (off >= half ? h->kiters : half);
-                it += std::min(end - off, it1 - it);
-                ++segs;
+            int seg = 0;
+            for (int r = 0; r < GRAM_RMAX; ++r) {
+                int64_t it = ranges[((size_t)w * GRAM_RMAX + r) * 2];
+                const int64_t it1 = ranges[((size_t)w * GRAM_RMAX + r) * 2 + 1];
+                while (it < it1) {
+                    const int64_t e = it / kit, off = it - e * kit;
+                    const bool dual = tl[(size_t)e].d1 >= 0;
+                    const int hs = (dual && off >= half) ? 1 : 0;
+                    const int64_t lo = dual ? (hs ? half : 0) : 0, hi = dual ? (hs ? kit : half) : kit;
+                    const int64_t ue = std::min(hi, off + (it1 - it));
+                    const bool whole = (off == lo && ue == hi);
+                    if (dual || !whole) cl[(size_t)e * 2 + hs].push_back(Contrib{off, w, seg});
+                    it += ue - off;
+                    ++seg;
+                }
             }
-            nslot = std::max(nslot, segs);
+            nslot = std::max(nslot, seg);
         }
         h->gram_nslot = nslot;
+        std::vector<int32_t> cstart(cl.size() + 1, 0), contrib;
+        for (size_t i = 0; i < cl.size(); ++i) {
+            std::sort(cl[i].begin(), cl[i].end(), [](const Contrib& a, const Contrib& b) { return a.kb < b.kb; });
+            for (const Contrib& c : cl[i]) { contrib.push_back(c.w); contrib.push_back(c.slot); }
+            cstart[i + 1] = (int32_t)(contrib.size() / 2);
+        }
+        if (contrib.empty()) contrib.push_back(0);
+        ACC_HIP(hipMalloc(&h->wg_ranges, sizeof(int64_t) * ranges.size()));
+        ACC_HIP(hipMemcpy(h->wg_ranges, ranges.data(), sizeof(int64_t) * ranges.size(), hipMemcpyHostToDevice));
+        ACC_HIP(hipMalloc(&h->gram_cstart, sizeof(int32_t) * cstart.size()));
+        ACC_HIP(hipMemcpy(h->gram_cstart, cstart.data(), sizeof(int32_t) * cstart.size(), hipMemcpyHostToDevice));
+        ACC_HIP(hipMalloc(&h->gram_contrib, sizeof(int32_t) * contrib.size()));
+        ACC_HIP(hipMemcpy(h->gram_contrib, contrib.data(), sizeof(int32_t) * contrib.size(), hipMemcpyHostToDevice));
     }
     ACC_HIP(hipMalloc(&h->slabs, sizeof(double) * (size_t)grid * h->gram_nslot * BM * BN));
 
@@ -1406,19 +1475,19 @@ static void gram_launch_t(accbpg_dopt* h, const double* x, double* gram) {
     if constexpr (!T::EDGE && T::BM == 256) {
         if (h->use_glds || h->has_duals)
             gram_streamk_glds_kernel<T><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
-                h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->gram_nslot, h->slabs, gram, h->m);
+                h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m);
         else
             gram_streamk_kernel<T><<<h->gram_grid, NTHREADS, T::LDS_BYTES, h->stream>>>(
-                h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->gram_nslot, h->slabs, gram, h->m,
+                h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m,
                 h->vec_ok);
     } else {
         gram_streamk_kernel<T><<<h->gram_grid, NTHREADS, T::LDS_BYTES, h->stream>>>(
-            h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->gram_nslot, h->slabs, gram, h->m,
+            h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m,
             h->vec_ok);
     }
     prof_end(h, PROF_GRAM);
     prof_begin(h, PROF_GRAMFIX);
-    gram_fixup_kernel<T><<<h->ntiles * 2 * T::MI * FIX_PJ, NTHREADS, 0, h->stream>>>(h->tiles, h->ntiles, h->kiters, h->gram_per, h->gram_nslot,
+    gram_fixup_kernel<T><<<h->ntiles * 2 * T::MI * FIX_PJ, NTHREADS, 0, h->stream>>>(h->tiles, h->gram_cstart, h->gram_contrib, h->gram_nslot,
                                                                 h->slabs, gram, h->m, h->m);
     prof_end(h, PROF_GRAMFIX);
 }
@@ -1434,10 +1503,10 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
     auto launch = [&]() {
 #define ACC_LAUNCH_VAR(VV)                                                                                       \
     gram_streamk_kernel<T, VV><<<h->gram_grid, NTHREADS, T::LDS_BYTES, h->stream>>>(                             \
-        h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->gram_nslot, h->slabs, h->Tbuf, h->m, h->vec_ok)
+        h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, h->Tbuf, h->m, h->vec_ok)
 #define ACC_LAUNCH_G(GG)                                                                                         \
     gram_streamk_glds_kernel<T, GG><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(                      \
-        h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->gram_nslot, h->slabs, h->Tbuf, h->m)
+        h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, h->Tbuf, h->m)
         switch (var) {
             case 10: ACC_LAUNCH_G(0); break;
             case 11: ACC_LAUNCH_G(1); break;
@@ -1491,11 +1560,11 @@ int launch_gram(accbpg_dopt* h, const double* x, double* gram) {
         using T = TileMid<false, false>;
         prof_begin(h, PROF_GRAM);
         gram_streamk_glds_kernel<T, 0, 2, 2><<<h->gram_grid, NTHREADS, 2 * T::G_STAGE * 8, h->stream>>>(
-            h->V, h->ldv, h->m, h->n, x, h->tiles, h->ntiles, h->kiters, h->gram_per, h->gram_nslot, h->slabs, gram, h->m);
+            h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m);
         prof_end(h, PROF_GRAM);
         prof_begin(h, PROF_GRAMFIX);
-        gram_fixup_kernel<T><<<h->ntiles * 2 * T::MI * FIX_PJ, NTHREADS, 0, h->stream>>>(h->tiles, h->ntiles, h->kiters,
-                                                                            h->gram_per, h->gram_nslot, h->slabs, gram, h->m, h->m);
+        gram_fixup_kernel<T><<<h->ntiles * 2 * T::MI * FIX_PJ, NTHREADS, 0, h->stream>>>(h->tiles, h->gram_cstart, h->gram_contrib,
+                                                                            h->gram_nslot, h->slabs, gram, h->m, h->m);
         prof_end(h, PROF_GRAMFIX);
         ACC_HIP(hipGetLastError());
         return ACCBPG_OK;

@@ -76,6 +76,9 @@ struct accbpg_dopt {
     double* Tbuf = nullptr;     // m*m : scratch of the inverse merges / FW refactorisation
     double* slabs = nullptr;    // stream-K partial accumulators
     accbpg::TileRC* tiles = nullptr;
+    int64_t* wg_ranges = nullptr;     // [gram_grid][GRAM_RMAX][2] unit ranges of the Gram stream-K walk
+    int32_t* gram_cstart = nullptr;   // per (entry, half): first index into gram_contrib
+    int32_t* gram_contrib = nullptr;  // (workgroup, slab slot) pairs in k order
     int ntiles = 0, gram_grid = 0, gram_per = 0, gram_nslot = 2;
     int64_t kiters = 0;
     double* dscal = nullptr;    // device scalars
