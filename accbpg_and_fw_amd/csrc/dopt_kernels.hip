@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_kernel(
 // slabs): global_load_lds_dwordx4 into three rotating swizzled stages, loads two k-steps ahead,
 // counted vmcnt + raw barrier, x applied to the A fragments after the LDS read.
 // GV (timing ablations only): bit 0 = no loads inside the k-loop, bit 1 = no wait + barrier,
-// bit 2 = no fragment reads, bit 3 = barrier without the vmcnt wait.
+// bit 2 = no fragment reads, bit 3 = barrier without the vmcnt wait, bit 4 = half of the fragment reads.
 // NSTAGE = 3: loads two k-steps ahead, one workgroup per CU (big tile);
 // NSTAGE = 2: loads one k-step ahead, issued right after the barrier into the buffer just read --
 //             for the mid tile at two workgroups per CU, where the co-resident workgroup hides the waits.
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
                 __builtin_amdgcn_sched_barrier(0);
                 t.template scale_frag<1>();
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(GV & 4)) t.template read_frag_g<0, true>(st, 2);
+                if constexpr (!(GV & 4) && !(GV & 16)) t.template read_frag_g<0, true>(st, 2);
                 __builtin_amdgcn_sched_barrier(0);
                 t.template mma_frag<1>();
                 __builtin_amdgcn_sched_barrier(0);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
                 }
                 cur = (cur + 1 == 3) ? 0 : cur + 1;
                 // (after the last step this reads the redundant, already landed copy of stage klast)
-                if constexpr (!(GV & 4)) t.template read_frag_g<0, true>(lds + cur * T::G_STAGE, 0);
+                if constexpr (!(GV & 4) && !(GV & 16)) t.template read_frag_g<0, true>(lds + cur * T::G_STAGE, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 t.template mma_frag<1>();
                 __builtin_amdgcn_sched_barrier(0);
@@ -617,17 +617,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_ops_kernel(const GemmOp* __r
     const bool vb = ((reinterpret_cast<uintptr_t>(op.B) & 15) == 0) && ((op.ldb & 1) == 0);
     T t;
     t.zero();
-    const int64_t ksteps = (op.K + BK - 1) / BK;
+    int64_t ksteps = (op.K + BK - 1) / BK;
+    int64_t ks0 = 0;
+    if (op.tri & 1) ks0 = col0 / BK;                                        // triangular B: leading zeros
+    if (op.tri & 2) ksteps = min(ksteps, (row0 + T::BM + BK - 1) / BK);     // triangular A: trailing zeros
     auto gload = [&](int64_t ks) {
         t.gload_A(op.A, op.lda, row0, op.M, ks * BK, op.K, va);
         if constexpr (T::BKM) t.gload_B_km(op.B, op.ldb, col0, op.N, ks * BK, op.K, vb);
         else t.gload_B_kc(op.B, op.ldb, col0, op.N, ks * BK, op.K, vb);
     };
-    gload(0);
+    gload(ks0);
     t.sstore(lds);
     __syncthreads();
     int cur = 0;
-    for (int64_t ks = 0; ks < ksteps; ++ks) {
+    for (int64_t ks = ks0; ks < ksteps; ++ks) {
         const bool more = ks + 1 < ksteps;
         if (more) gload(ks + 1);
         t.compute(lds + cur * T::STAGE_ELEMS);
@@ -1426,11 +1429,13 @@ int build_plans(accbpg_dopt* h) {
             a.B = h->Wbuf + r1 * m + r1; a.ldb = m;                     // W11 (s1 x s1), B[k][col]
             a.C = h->Tbuf + r2 * m + r1; a.ldc = m;                     // T1  (s2 x s1)
             a.M = (int)s2; a.N = (int)s1; a.K = (int)s1; a.lower_only = 0; a.alpha = 1.0; a.beta = 0.0;
+            a.tri = 1;                                                  // W11 is lower triangular
             GemmOp b{};
             b.A = h->Wbuf + r2 * m + r2; b.lda = m;                     // W22 (s2 x s2)
             b.B = h->Tbuf + r2 * m + r1; b.ldb = m;                     // T1, B[k][col]
             b.C = h->Wbuf + r2 * m + r1; b.ldc = m;                     // W21
             b.M = (int)s2; b.N = (int)s1; b.K = (int)s2; b.lower_only = 0; b.alpha = -1.0; b.beta = 0.0;
+            b.tri = 2;                                                  // W22 is lower triangular
             first.push_back(a);
             second.push_back(b);
             maxm = std::max(maxm, (int)s2);
@@ -1515,6 +1520,7 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
             case 14: ACC_LAUNCH_G(4); break;
             case 15: ACC_LAUNCH_G(8); break;
             case 16: ACC_LAUNCH_G(7); break;
+            case 17: ACC_LAUNCH_G(16); break;
             case 0: ACC_LAUNCH_VAR(0); break;
             case 1: ACC_LAUNCH_VAR(1); break;
             case 2: ACC_LAUNCH_VAR(2); break;
@@ -1529,6 +1535,7 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
     ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 4>, T::G_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 8>, T::G_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 7>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 16>, T::G_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 1>, T::LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 2>, T::LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 3>, T::LDS_BYTES));

@@ -35,6 +35,7 @@ struct GemmOp {
     int64_t lda, ldb, ldc;
     int32_t M, N, K;
     int32_t lower_only;     // skip tiles / elements strictly above the diagonal of C
+    int32_t tri;            // bit 0: B[k][col] is zero for k < col; bit 1: A[row][k] is zero for k > row (k ranges are cut)
     double alpha, beta;
 };
 

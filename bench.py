@@ -244,7 +244,10 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            if use_nccl:
+                dist.barrier(device_ids=[torch.cuda.current_device()])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     if shard and args.workload.startswith("fw"):
