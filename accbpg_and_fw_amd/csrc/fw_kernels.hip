@@ -122,7 +122,26 @@ __global__ __launch_bounds__(FB) void fw_gemv_h_kernel(const double* __restrict_
     if (row >= m) return;
     const double* hr = H + row * m;
     double s = 0.0;
-    for (int64_t c = lane; c < m; c += 64) s = fma(hr[c], vp[c], s);
+    if ((m & 1) == 0) {
+        // 16-byte loads, four independent accumulators (H rows are 16-byte aligned when m is even)
+        const double2* h2 = reinterpret_cast<const double2*>(hr);
+        const double2* v2 = reinterpret_cast<const double2*>(vp);
+        const int64_t n2 = m >> 1;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int64_t c = lane;
+        for (; c + 64 < n2; c += 128) {
+            const double2 a = h2[c], b = h2[c + 64], x = v2[c], y = v2[c + 64];
+            s0 = fma(a.x, x.x, s0); s1 = fma(a.y, x.y, s1);
+            s2 = fma(b.x, y.x, s2); s3 = fma(b.y, y.y, s3);
+        }
+        for (; c < n2; c += 64) {
+            const double2 a = h2[c], x = v2[c];
+            s0 = fma(a.x, x.x, s0); s1 = fma(a.y, x.y, s1);
+        }
+        s = (s0 + s1) + (s2 + s3);
+    } else {
+        for (int64_t c = lane; c < m; c += 64) s = fma(hr[c], vp[c], s);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
     if (lane == 0) hv[row] = s;

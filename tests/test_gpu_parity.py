@@ -82,7 +82,7 @@ def test_func_grad_matches_reference_golden(acc, O, tag):
 @pytest.mark.parametrize("shape", [(13, 506, 0), (80, 200, 10), (100, 1001, 4), (333, 777, 5),
                                    (768, 2048, 6), (1024, 4096, 8), (1000, 3000, 9), (1280, 2560, 11),
                                    (1024, 4112, 12), (2304, 4608, 13), (1536, 2080, 14), (4096, 8192, 15),
-                                   (3072, 49152, 16)])
+                                   (3072, 49152, 16), (2560, 16384, 17), (1792, 57344, 18)])
 def test_func_grad_matches_oracle_ragged_sizes(acc, O, shape):
     """Sizes that are not tile multiples (odd n, odd m, big tile with edges); interior sizes whose
     Gram tile list holds dual diagonal tiles (even / odd count of them, short and long K ranges per
