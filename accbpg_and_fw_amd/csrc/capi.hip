@@ -71,10 +71,6 @@ extern "C" int accbpg_dopt_create(const double* V_dev, int64_t m, int64_t n, int
     ACC_HIP(hipHostMalloc(&h->hpin, sizeof(double) * 32, hipHostMallocDefault));
     const int64_t vws = std::max<int64_t>(vec_ws_doubles(n), 64 * n);
     ACC_HIP(hipMalloc(&h->vws, sizeof(double) * (size_t)vws));
-    {
-        const char* e = getenv("ACCBPG_GRAM_MID");     // development switch: 128x128 Gram tiles, 2 workgroups per CU
-        h->want_mid = (e != nullptr && e[0] == '1');
-    }
     int rc = build_plans(h);
     if (rc != ACCBPG_OK) { accbpg_dopt_destroy(h); return rc; }
     *out = h;

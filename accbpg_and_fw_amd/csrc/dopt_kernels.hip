@@ -144,11 +144,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_kernel(
 // counted vmcnt + raw barrier, x applied to the A fragments after the LDS read.
 // GV (timing ablations only): bit 0 = no loads inside the k-loop, bit 1 = no wait + barrier,
 // bit 2 = no fragment reads, bit 3 = barrier without the vmcnt wait, bit 4 = half of the fragment reads.
-// NSTAGE = 3: loads two k-steps ahead, one workgroup per CU (big tile);
-// NSTAGE = 2: loads one k-step ahead, issued right after the barrier into the buffer just read --
-//             for the mid tile at two workgroups per CU, where the co-resident workgroup hides the waits.
-template <class T, int GV = 0, int NSTAGE = 3, int WPS = 1>
-__global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
+template <class T, int GV = 0>
+__global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_glds_kernel(
     const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n, const double* __restrict__ x,
     const TileRC* __restrict__ tiles, const int64_t* __restrict__ wg_ranges, int64_t kiters, int nslot,
     double* __restrict__ slabs,
@@ -165,7 +162,7 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
         const int64_t kb = sg.kb, ke = sg.ke, row0 = sg.row0, col0 = sg.col0;
         const int64_t klast = ke - 1;
         t.zero();
-        if constexpr (NSTAGE == 3 && T::WAVES_N == 1) {
+        if constexpr (T::WAVES_N == 1) {
             if (sg.dual) {
                 // dual diagonal tile: A image = the band at k-step ks and at ks + K/2, no B image
                 constexpr int NLDD = T::G_NLD_DUAL;
@@ -228,94 +225,69 @@ __global__ __launch_bounds__(NTHREADS, WPS) void gram_streamk_glds_kernel(
             t.glds_x(x, ks * BK, st);
         };
         __builtin_amdgcn_s_barrier();                           // previous segment's readers are done
-        if constexpr (NSTAGE == 3) {
-            issue(kb, 0);
-            issue(min(kb + 1, klast), 1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");   // stage 0 landed (this wave's share)
-            __builtin_amdgcn_s_barrier();
-            int cur = 0;
-            // The barrier sits BEFORE the last fragment group's MFMAs: the first fragments of the next
-            // stage are read right behind it and land while those 32 MFMAs occupy the matrix pipe, so
-            // the pipe has work queued across the barrier instead of waiting out an LDS round trip.
-            t.template read_frag_g<0, true>(lds, 0);
-            // The schedule is pinned (sched_barrier): fragment reads of the next group first, then the
-            // x-scaling of the set that is about to be used (requested a whole group earlier), then the
-            // MFMAs; the loads of stage ks+2 are dealt out between the fragment rows of group 0.
-            static_assert(T::MI == 4, "group 0 is dealt out over four fragment rows");
-            constexpr int NP = T::G_NA + T::G_NB;
-            constexpr int P1 = (NP + 2) / 3, P2 = 2 * P1 < NP ? 2 * P1 : NP;
+        issue(kb, 0);
+        issue(min(kb + 1, klast), 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");   // stage 0 landed (this wave's share)
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        // The barrier sits BEFORE the last fragment group's MFMAs: the first fragments of the next
+        // stage are read right behind it and land while those 32 MFMAs occupy the matrix pipe, so
+        // the pipe has work queued across the barrier instead of waiting out an LDS round trip.
+        t.template read_frag_g<0, true>(lds, 0);
+        // The schedule is pinned (sched_barrier): fragment reads of the next group first, then the
+        // x-scaling of the set that is about to be used (requested a whole group earlier), then the
+        // MFMAs; the loads of stage ks+2 are dealt out between the fragment rows of group 0.
+        static_assert(T::MI == 4, "group 0 is dealt out over four fragment rows");
+        constexpr int NP = T::G_NA + T::G_NB;
+        constexpr int P1 = (NP + 2) / 3, P2 = 2 * P1 < NP ? 2 * P1 : NP;
 #pragma unroll 1
-            for (int64_t ks = kb; ks < ke; ++ks) {
-                int nx2 = cur + 2;
-                if (nx2 >= 3) nx2 -= 3;
-                const double* st = lds + cur * T::G_STAGE;
-                double* nst = lds + nx2 * T::G_STAGE;            // last read in step ks-1
-                const int64_t k2 = min(ks + 2, klast) * BK;
-                // (the scaling multiplies come BEFORE the next reads are issued: the wait in front of
-                //  them then covers only reads that were issued a whole group ago)
-                t.template scale_frag<0>();
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(GV & 4)) t.template read_frag_g<1, true>(st, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                t.template mma_row<0>(0);
-                if constexpr (!(GV & 1)) t.glds_issue_range(k2, k2, nst, 0, P1);
-                t.template mma_row<0>(1);
-                if constexpr (!(GV & 1)) t.glds_issue_range(k2, k2, nst, P1, P2);
-                t.template mma_row<0>(2);
-                if constexpr (!(GV & 1)) { t.glds_issue_range(k2, k2, nst, P2, NP); t.glds_x(x, k2, nst); }
-                t.template mma_row<0>(3);
-                __builtin_amdgcn_sched_barrier(0);
-                t.template scale_frag<1>();
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(GV & 4) && !(GV & 16)) t.template read_frag_g<0, true>(st, 2);
-                __builtin_amdgcn_sched_barrier(0);
-                t.template mma_frag<1>();
-                __builtin_amdgcn_sched_barrier(0);
-                t.template scale_frag<0>();
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (!(GV & 4)) t.template read_frag_g<1, true>(st, 3);
-                __builtin_amdgcn_sched_barrier(0);
-                t.template mma_frag<0>();
-                __builtin_amdgcn_sched_barrier(0);
-                t.template scale_frag<1>();
-                __builtin_amdgcn_sched_barrier(0);
-                // stage ks+1 (issued one step ago) must have landed: all but the newest NLD loads done;
-                // lgkmcnt(0): this wave's reads of stage ks are complete before others may overwrite it
-                if constexpr (!(GV & 2)) {
-                    if constexpr (GV & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLD) : "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
-                cur = (cur + 1 == 3) ? 0 : cur + 1;
-                // (after the last step this reads the redundant, already landed copy of stage klast)
-                if constexpr (!(GV & 4) && !(GV & 16)) t.template read_frag_g<0, true>(lds + cur * T::G_STAGE, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                t.template mma_frag<1>();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            issue(kb, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            issue(min(kb + 1, klast), 1);
-            int cur = 0;
-#pragma unroll 1
-            for (int64_t ks = kb; ks < ke; ++ks) {
-                const double* st = lds + cur * T::G_STAGE;
-                t.template read_frag_g<0, true>(st, 0);
-                t.template read_frag_g<1, true>(st, 1);
-                t.template scale_frag<0>(); t.template mma_frag<0>();
-                t.template read_frag_g<0, true>(st, 2);
-                t.template scale_frag<1>(); t.template mma_frag<1>();
-                t.template read_frag_g<1, true>(st, 3);
-                t.template scale_frag<0>(); t.template mma_frag<0>();
-                t.template scale_frag<1>(); t.template mma_frag<1>();
-                // stage ks+1 has landed and every wave is done reading stage ks ...
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int64_t ks = kb; ks < ke; ++ks) {
+            int nx2 = cur + 2;
+            if (nx2 >= 3) nx2 -= 3;
+            const double* st = lds + cur * T::G_STAGE;
+            double* nst = lds + nx2 * T::G_STAGE;            // last read in step ks-1
+            const int64_t k2 = min(ks + 2, klast) * BK;
+            // (the scaling multiplies come BEFORE the next reads are issued: the wait in front of
+            //  them then covers only reads that were issued a whole group ago)
+            t.template scale_frag<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(GV & 4)) t.template read_frag_g<1, true>(st, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            t.template mma_row<0>(0);
+            if constexpr (!(GV & 1)) t.glds_issue_range(k2, k2, nst, 0, P1);
+            t.template mma_row<0>(1);
+            if constexpr (!(GV & 1)) t.glds_issue_range(k2, k2, nst, P1, P2);
+            t.template mma_row<0>(2);
+            if constexpr (!(GV & 1)) { t.glds_issue_range(k2, k2, nst, P2, NP); t.glds_x(x, k2, nst); }
+            t.template mma_row<0>(3);
+            __builtin_amdgcn_sched_barrier(0);
+            t.template scale_frag<1>();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(GV & 4) && !(GV & 16)) t.template read_frag_g<0, true>(st, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            t.template mma_frag<1>();
+            __builtin_amdgcn_sched_barrier(0);
+            t.template scale_frag<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!(GV & 4)) t.template read_frag_g<1, true>(st, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            t.template mma_frag<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            t.template scale_frag<1>();
+            __builtin_amdgcn_sched_barrier(0);
+            // stage ks+1 (issued one step ago) must have landed: all but the newest NLD loads done;
+            // lgkmcnt(0): this wave's reads of stage ks are complete before others may overwrite it
+            if constexpr (!(GV & 2)) {
+                if constexpr (GV & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLD) : "memory");
                 __builtin_amdgcn_s_barrier();
-                issue(min(ks + 2, klast), cur);                 // ... whose buffer takes stage ks+2
-                cur ^= 1;
             }
+            cur = (cur + 1 == 3) ? 0 : cur + 1;
+            // (after the last step this reads the redundant, already landed copy of stage klast)
+            if constexpr (!(GV & 4) && !(GV & 16)) t.template read_frag_g<0, true>(lds + cur * T::G_STAGE, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            t.template mma_frag<1>();
+            __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // tail loads / reads retire before LDS is reused
         if (sg.whole) {
@@ -1235,18 +1207,16 @@ void prof_end(accbpg_dopt* h, ProfKind k) {
 int build_plans(accbpg_dopt* h) {
     const int64_t m = h->m;
     // ---- Gram tile list (lower tiles) and stream-K partition
-    // mid tile (two workgroups per CU) for interior big problems when selected
     const bool interior256 = h->vec_ok && (m % 256 == 0) && (h->n % BK == 0);
-    h->gram_mid = h->big && interior256 && h->want_mid;
-    const int BM = h->gram_mid ? 128 : (h->big ? TileBig<false>::BM : TileSmall<false>::BM);
-    const int BN = h->gram_mid ? 128 : (h->big ? TileBig<false>::BN : TileSmall<false>::BN);
+    const int BM = h->big ? TileBig<false>::BM : TileSmall<false>::BM;
+    const int BN = h->big ? TileBig<false>::BN : TileSmall<false>::BN;
     std::vector<TileRC> tl;
     const int nrb = (int)((m + BM - 1) / BM), ncb = (int)((m + BN - 1) / BN);
     h->kiters = (h->n + BK - 1) / BK;
     // 256x128 tiles: the tile (rb, 2rb+1) next to the diagonal holds one useful 128 x 128 block, the odd
     // diagonal block 2rb+1, under 128 rows that lie strictly above the diagonal.  On the direct-to-LDS
     // path those blocks run as dual tiles instead (half of K each at full MFMA work), two per entry.
-    const bool duals = h->big && !h->gram_mid && interior256 && h->use_glds && (h->kiters % 2 == 0) && BM == 2 * BN;
+    const bool duals = h->big && interior256 && h->use_glds && (h->kiters % 2 == 0) && BM == 2 * BN;
     std::vector<int> lone;
     for (int rb = 0; rb < nrb; ++rb)
         for (int cb = 0; cb < ncb; ++cb)
@@ -1260,7 +1230,7 @@ int build_plans(accbpg_dopt* h) {
     h->has_duals = lone.size() >= 2;
     h->ntiles = (int)tl.size();
     const int64_t total = (int64_t)h->ntiles * h->kiters;
-    int grid = (h->big && !h->gram_mid) ? h->num_cu : 2 * h->num_cu;
+    int grid = h->big ? h->num_cu : 2 * h->num_cu;
     if (grid > total) grid = (int)total;
     if (grid < h->ntiles && total / h->ntiles < 8) grid = h->ntiles;   // tiny K: one tile per workgroup
     int64_t per = (total + grid - 1) / grid;
@@ -1280,7 +1250,7 @@ int build_plans(accbpg_dopt* h) {
     std::vector<int64_t> ranges((size_t)grid * GRAM_RMAX * 2, 0);
     const int64_t q = kit / per, rem = kit % per;
     // (a tail workgroup crosses at most per/rem + 2 remainders)
-    const bool aligned = h->big && !h->gram_mid && q >= 1 && rem > 0 && (int64_t)h->ntiles * q < grid &&
+    const bool aligned = h->big && q >= 1 && rem > 0 && (int64_t)h->ntiles * q < grid &&
                          per / rem + 2 <= GRAM_RMAX;
     if (aligned) {
         // compact order of the entries: 4 x 8 blocks of tiles
@@ -1467,7 +1437,6 @@ int build_plans(accbpg_dopt* h) {
     ACC_TRY(set_lds(gemm_ops_kernel<TileSmall<false>>, TileSmall<false>::LDS_BYTES));
     ACC_TRY(set_lds(chol_step_kernel, CHOL_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>>, TileBig<false, false>::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<TileMid<false, false>, 0, 2, 2>, 2 * TileMid<false, false>::G_STAGE * 8));
     ACC_TRY(set_lds(colnorm_glds_kernel<TileBig<true, false>>, TileBig<true, false>::G_LDS_BYTES + 4 * 128 * 8));
     ACC_TRY(set_lds(gemm_big_kernel<TileBig<true>>, TileBig<true>::LDS_BYTES));
     ACC_TRY(set_lds(gemm_big_kernel<TileBig<false>>, TileBig<false>::LDS_BYTES));
@@ -1556,25 +1525,12 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
 
 int launch_gram(accbpg_dopt* h, const double* x, double* gram) {
     bool xal = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    if (!xal && (h->has_duals || h->gram_mid)) {
+    if (!xal && h->has_duals) {
         // the tile list was built for the direct-to-LDS kernel, which reads x in 16-byte pieces
         if (!h->xbuf) ACC_HIP(hipMalloc(&h->xbuf, sizeof(double) * (size_t)h->n));
         ACC_HIP(hipMemcpyAsync(h->xbuf, x, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
         x = h->xbuf;
         xal = true;
-    }
-    if (h->gram_mid && xal) {
-        using T = TileMid<false, false>;
-        prof_begin(h, PROF_GRAM);
-        gram_streamk_glds_kernel<T, 0, 2, 2><<<h->gram_grid, NTHREADS, 2 * T::G_STAGE * 8, h->stream>>>(
-            h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m);
-        prof_end(h, PROF_GRAM);
-        prof_begin(h, PROF_GRAMFIX);
-        gram_fixup_kernel<T><<<h->ntiles * 2 * T::MI * FIX_PJ, NTHREADS, 0, h->stream>>>(h->tiles, h->gram_cstart, h->gram_contrib,
-                                                                            h->gram_nslot, h->slabs, gram, h->m, h->m);
-        prof_end(h, PROF_GRAMFIX);
-        ACC_HIP(hipGetLastError());
-        return ACCBPG_OK;
     }
     if (h->big) {
         const bool interior = h->vec_ok && xal && (h->m % 256 == 0) && (h->n % BK == 0);

@@ -98,8 +98,6 @@ struct accbpg_dopt {
     double *fw_x = nullptr, *fw_w = nullptr, *fw_H = nullptr, *fw_hv = nullptr;
     bool fw_ready = false;
 
-    bool want_mid = false;      // Gram on 128x128 tiles, two workgroups per CU (set before build_plans)
-    bool gram_mid = false;
     bool use_glds = true;       // direct-to-LDS staging for interior big tiles (debug switch)
     bool has_duals = false;     // the Gram tile list holds dual diagonal tiles (direct-to-LDS kernel only)
     int chol_dbg = 0;           // timing ablation bits for chol_step_kernel (0 in production)

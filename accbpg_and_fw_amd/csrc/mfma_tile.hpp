@@ -599,8 +599,5 @@ __device__ __forceinline__ void sched_post_barrier() {
 // pieces (Cholesky trailing updates, inverse merges, small instances).
 template <bool BKM, bool EDGE = true> using TileBig = Tile<256, 128, 64, 128, BKM, EDGE>;
 template <bool BKM, bool EDGE = true> using TileSmall = Tile<64, 64, 32, 32, BKM, EDGE>;
-// "mid": 128x128 tile, wave tile 64x64 (128 accumulator registers): two workgroups per CU, i.e. two
-// waves per SIMD that cover each other's barrier and load waits
-template <bool BKM, bool EDGE = true> using TileMid = Tile<128, 128, 64, 64, BKM, EDGE>;
 
 }  // namespace accbpg
