@@ -442,7 +442,8 @@ def test_large_fw_2048x32768(large, acc):
 
 
 # ------------------------------------------------------------------ sharding (one device, logical shards)
-@pytest.mark.parametrize("shape,parts", [((96, 1000), 3), ((1024, 4096), 8), ((300, 1111), 4)])
+@pytest.mark.parametrize("shape,parts", [((96, 1000), 3), ((1024, 4096), 8), ((300, 1111), 4), ((2048, 8192), 4),
+                                         ((4096, 16384), 2)])
 def test_logical_shards_match_single_device(acc, shape, parts):
     """Design-point sharding with the all-reduce replaced by an in-process sum:
     same f and g as the unsharded objective, and a solver runs on it unchanged."""
