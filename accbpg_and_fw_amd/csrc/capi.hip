@@ -80,7 +80,7 @@ extern "C" int accbpg_dopt_create(const double* V_dev, int64_t m, int64_t n, int
 extern "C" int accbpg_dopt_destroy(accbpg_dopt* h) {
     if (!h) return ACCBPG_OK;
     hipFree(h->Lbuf); hipFree(h->Wbuf); hipFree(h->Tbuf); hipFree(h->slabs); hipFree(h->tiles); hipFree(h->wg_ranges); hipFree(h->gram_cstart); hipFree(h->gram_contrib);
-    hipFree(h->dscal); hipFree(h->dflag); hipFree(h->vws); hipFree(h->xbuf); hipFree(h->ops); hipFree(h->chol_op);
+    hipFree(h->dscal); hipFree(h->dflag); hipFree(h->vws); hipFree(h->xbuf); hipFree(h->ops); hipFree(h->chol_op); hipFree(h->red); hipFree(h->Pbuf);
     hipFree(h->fw_x); hipFree(h->fw_w); hipFree(h->fw_H); hipFree(h->fw_hv);
     if (h->hpin) hipHostFree(h->hpin);
     for (auto& p : h->prof)
@@ -130,7 +130,7 @@ extern "C" int accbpg_dopt_func_grad_begin(accbpg_dopt* h, const double* x_dev, 
     if (!h || !x_dev || flag < 0 || flag > 2) return ACCBPG_ERR_ARG;
     if (flag != 0 && !g_dev) return ACCBPG_ERR_ARG;
     ACC_TRY(launch_gram(h, x_dev, h->Lbuf));
-    ACC_TRY(launch_cholesky(h, h->Lbuf));                       // resets the flags first
+    ACC_TRY(launch_cholesky(h, h->Lbuf, flag != 0 ? h->Wbuf : nullptr));   // resets the flags first
     check_nonneg_kernel<<<64, 256, 0, h->stream>>>(x_dev, h->n, h->dflag);      // functions.py:45
     if (flag != 0) {
         ACC_TRY(launch_trtri(h));
@@ -199,7 +199,7 @@ extern "C" int accbpg_dopt_eval_gram(accbpg_dopt* h, const double* gram_dev, int
     if (flag != 0 && !g_dev) return ACCBPG_ERR_ARG;
     if (gram_dev != h->Lbuf)
         ACC_HIP(hipMemcpyAsync(h->Lbuf, gram_dev, sizeof(double) * h->m * h->m, hipMemcpyDeviceToDevice, h->stream));
-    ACC_TRY(launch_cholesky(h, h->Lbuf));
+    ACC_TRY(launch_cholesky(h, h->Lbuf, flag != 0 ? h->Wbuf : nullptr));
     if (flag != 0) {
         ACC_TRY(launch_trtri(h));
         ACC_TRY(launch_colnorm(h, h->Wbuf, g_dev, -1.0));

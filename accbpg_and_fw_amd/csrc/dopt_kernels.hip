@@ -591,8 +591,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_ops_kernel(const GemmOp* __r
     t.zero();
     int64_t ksteps = (op.K + BK - 1) / BK;
     int64_t ks0 = 0;
-    if (op.tri & 1) ks0 = col0 / BK;                                        // triangular B: leading zeros
-    if (op.tri & 2) ksteps = min(ksteps, (row0 + T::BM + BK - 1) / BK);     // triangular A: trailing zeros
+    if (op.tri & 1) ks0 = max((int64_t)0, col0 - op.koff) / BK;             // triangular B: leading zeros
+    if (op.tri & 2) ksteps = min(ksteps, max((int64_t)0, row0 + T::BM - op.koff + BK - 1) / BK);   // triangular A: trailing zeros
+    if (ks0 >= ksteps) {                                                    // nothing but zeros in this piece
+        t.store_C(op.C, op.ldc, row0, col0, op.M, op.N, op.alpha, op.beta, op.lower_only != 0);
+        return;
+    }
     auto gload = [&](int64_t ks) {
         t.gload_A(op.A, op.lda, row0, op.M, ks * BK, op.K, va);
         if constexpr (T::BKM) t.gload_B_km(op.B, op.ldb, col0, op.N, ks * BK, op.K, vb);
@@ -611,6 +615,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_ops_kernel(const GemmOp* __r
         cur ^= 1;
     }
     t.store_C(op.C, op.ldc, row0, col0, op.M, op.N, op.alpha, op.beta, op.lower_only != 0);
+}
+
+// split-K reduction: C = sum of the ns partial products (fixed order)
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const RedOp* __restrict__ reds) {
+    const RedOp r = reds[blockIdx.y];
+    const int64_t total = (int64_t)r.M * r.N;
+    const int64_t stride = (int64_t)gridDim.x * 256 * 2;
+    for (int64_t e = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x); e < total; e += stride) {
+        double2 acc = *reinterpret_cast<const double2*>(r.P + e);
+        for (int p = 1; p < r.ns; ++p) {
+            const double2 v = *reinterpret_cast<const double2*>(r.P + (int64_t)p * total + e);
+            acc.x += v.x;
+            acc.y += v.y;
+        }
+        const int64_t row = e / r.N, col = e - row * r.N;
+        *reinterpret_cast<double2*>(r.C + row * r.ldc + col) = acc;
+    }
 }
 
 // same loop on the big tile, single product (unit-test hook and large merges)
@@ -1002,7 +1023,8 @@ __device__ __forceinline__ void trsm64_blk(double* __restrict__ Xs, const double
 
 __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restrict__ A, int64_t lda, int64_t m,
                                                                int kprev, int T, double* __restrict__ logdet,
-                                                               int* __restrict__ flags, int dbg) {
+                                                               int* __restrict__ flags, int dbg,
+                                                               double* __restrict__ Winv) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* Ak = lds;                       // 64 x SQ : L(i,kprev) operand image
     double* Bk = Ak + NB * SQ;              // 64 x SQ : L(kc,kprev) (or L(j,kprev)) operand image
@@ -1097,6 +1119,20 @@ __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restri
         if (tid == 0) {
             *logdet += 2.0 * (red[0] + red[1] + red[2] + red[3]);
             if (bad) flags[FLAG_NOT_PD] = 1;
+        }
+        if (Winv != nullptr) {
+            // inverse of the diagonal block for the gradient's W = L^-1, off the critical path (the other
+            // panel workgroups are in their panel solve meanwhile): X L^T = I gives X = W^T
+            __syncthreads();
+            for (int e = tid; e < NB * NB; e += NTHREADS) S[(e >> 6) * SP + (e & 63)] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
+            __syncthreads();
+            trsm64_blk(S, Lo, Ak);
+            __syncthreads();
+            double* Wkk = Winv + (int64_t)kc * NB * lda + (int64_t)kc * NB;
+            for (int e = tid; e < NB * NB; e += NTHREADS) {
+                const int r = e >> 6, c = e & 63;
+                if (r < bs && c < bs) Wkk[(int64_t)r * lda + c] = (c <= r) ? S[c * SP + r] : 0.0;
+            }
         }
         return;
     }
@@ -1379,16 +1415,19 @@ int build_plans(accbpg_dopt* h) {
     }
     ACC_HIP(hipMalloc(&h->slabs, sizeof(double) * (size_t)grid * h->gram_nslot * BM * BN));
 
-    // ---- inverse merge plan: binary tree over the NB-blocks of L
+    // ---- inverse merge plan: binary tree over the NB-blocks of L.
+    // Per level two products: T1 = L21 * W11, then W21 = -W22 * T1.  The 64 x 64-tile kernel is bound by
+    // the latency of its k-steps, and the top levels have few tiles with long K: products with K >= 512
+    // are cut into pieces of 256 along K (written to Pbuf, zero ranges of the triangular operands
+    // skipped per piece) and summed by a reduction launch in a fixed order.
     const int T = (int)((m + NB - 1) / NB);
     h->ops_host.clear();
-    h->level_begin.clear();
-    h->level_maxm.clear();
-    h->level_maxn.clear();
+    h->merge_stages.clear();
+    std::vector<RedOp> reds;
+    constexpr int64_t KP = 256, KSPLIT_MIN = 512;
+    ACC_HIP(hipMalloc(&h->Pbuf, sizeof(double) * (size_t)m * m));
     for (int span = 1; span < T; span *= 2) {
-        // two op lists per level: first T1 = L21 * W11, then W21 = -W22 * T1
         std::vector<GemmOp> first, second;
-        int maxm = 0, maxn = 0;
         for (int g = 0; g + span < T; g += 2 * span) {
             const int64_t r1 = (int64_t)g * NB;                         // left group rows/cols start
             const int64_t s1 = (int64_t)span * NB;                      // left size (always full)
@@ -1408,20 +1447,49 @@ int build_plans(accbpg_dopt* h) {
             b.tri = 2;                                                  // W22 is lower triangular
             first.push_back(a);
             second.push_back(b);
-            maxm = std::max(maxm, (int)s2);
-            maxn = std::max(maxn, (int)s1);
         }
-        h->level_begin.push_back((int)h->ops_host.size());
-        h->ops_host.insert(h->ops_host.end(), first.begin(), first.end());
-        h->level_maxm.push_back(maxm); h->level_maxn.push_back(maxn);
-        h->level_begin.push_back((int)h->ops_host.size());
-        h->ops_host.insert(h->ops_host.end(), second.begin(), second.end());
-        h->level_maxm.push_back(maxm); h->level_maxn.push_back(maxn);
+        for (std::vector<GemmOp>* list : {&first, &second}) {
+            // split when every product of the list is a whole number of K pieces (full-size groups; N even)
+            bool split = !list->empty();
+            size_t pdoubles = 0;
+            for (const GemmOp& o : *list) {
+                split = split && o.K >= KSPLIT_MIN && o.K % KP == 0 && (o.N % 2 == 0) && (o.ldc % 2 == 0);
+                pdoubles += (size_t)(o.K / KP) * o.M * o.N;
+            }
+            split = split && pdoubles <= (size_t)m * m;
+            accbpg_dopt::MergeStage st{0, (int)h->ops_host.size(), 0, 0, 0};
+            accbpg_dopt::MergeStage rs{1, (int)reds.size(), 0, 0, 0};
+            double* pb = h->Pbuf;
+            for (const GemmOp& o : *list) {
+                st.maxm = std::max(st.maxm, o.M); st.maxn = std::max(st.maxn, o.N);
+                if (!split) { h->ops_host.push_back(o); continue; }
+                const int ns = (int)(o.K / KP);
+                RedOp r{o.C, pb, o.ldc, o.M, o.N, ns, 0};
+                reds.push_back(r);
+                rs.maxm = std::max(rs.maxm, o.M * o.N);
+                for (int p = 0; p < ns; ++p) {
+                    GemmOp q = o;
+                    q.A = o.A + p * KP;                                 // A[row][k]: k is the fast index
+                    q.B = o.B + p * KP * o.ldb;                         // B[k][col]
+                    q.K = (int)KP;
+                    q.koff = (int)(p * KP);
+                    q.C = pb; q.ldc = o.N;
+                    pb += (size_t)o.M * o.N;
+                    h->ops_host.push_back(q);
+                }
+            }
+            st.end = (int)h->ops_host.size();
+            h->merge_stages.push_back(st);
+            if (split) { rs.end = (int)reds.size(); h->merge_stages.push_back(rs); }
+        }
     }
-    h->level_begin.push_back((int)h->ops_host.size());
     if (!h->ops_host.empty()) {
         ACC_HIP(hipMalloc(&h->ops, sizeof(GemmOp) * h->ops_host.size()));
         ACC_HIP(hipMemcpy(h->ops, h->ops_host.data(), sizeof(GemmOp) * h->ops_host.size(), hipMemcpyHostToDevice));
+    }
+    if (!reds.empty()) {
+        ACC_HIP(hipMalloc(&h->red, sizeof(RedOp) * reds.size()));
+        ACC_HIP(hipMemcpy(h->red, reds.data(), sizeof(RedOp) * reds.size(), hipMemcpyHostToDevice));
     }
     ACC_HIP(hipMalloc(&h->chol_op, sizeof(GemmOp) * (size_t)(T + 1)));
 
@@ -1558,7 +1626,7 @@ int launch_gemm_ops(const GemmOp* ops_dev, int nops, int maxM, int maxN, bool b_
 
 // In-place Cholesky of the lower triangle of A (m x m, ld m).  Resets and fills dscal[0] (log det)
 // and dflag[FLAG_NOT_PD].  T = ceil(m/64) launches.
-int launch_cholesky(accbpg_dopt* h, double* A) {
+int launch_cholesky(accbpg_dopt* h, double* A, double* Winv) {
     const int64_t m = h->m;
     const int T = (int)((m + NB - 1) / NB);
     prof_begin(h, PROF_CHOL);
@@ -1569,8 +1637,9 @@ int launch_cholesky(accbpg_dopt* h, double* A) {
         const int R = T - (kc + 1);
         const int nupd = (kprev >= 0) ? R * (R + 1) / 2 : 0;
         chol_step_kernel<<<npanel + nupd, NTHREADS, CHOL_LDS_BYTES, h->stream>>>(A, m, m, kprev, T, h->dscal,
-                                                                                 h->dflag, h->chol_dbg);
+                                                                                 h->dflag, h->chol_dbg, Winv);
     }
+    h->diag_inv_ready = (Winv != nullptr);
     prof_end(h, PROF_CHOL);
     ACC_HIP(hipGetLastError());
     return ACCBPG_OK;
@@ -1581,11 +1650,16 @@ int launch_trtri(accbpg_dopt* h) {
     const int64_t m = h->m;
     const int T = (int)((m + NB - 1) / NB);
     prof_begin(h, PROF_TRTRI);
-    trtri_diag_kernel<<<T, 64, 0, h->stream>>>(h->Lbuf, m, h->Wbuf, m, m);
-    const int nlev = (int)h->level_maxm.size();
-    for (int l = 0; l < nlev; ++l) {
-        const int b = h->level_begin[l], e = h->level_begin[l + 1];
-        ACC_TRY(launch_gemm_ops(h->ops + b, e - b, h->level_maxm[l], h->level_maxn[l], true, h->stream));
+    // (the factorisation leaves the inverses of the diagonal blocks in Wbuf when it was asked to)
+    if (!h->diag_inv_ready) trtri_diag_kernel<<<T, 64, 0, h->stream>>>(h->Lbuf, m, h->Wbuf, m, m);
+    h->diag_inv_ready = false;
+    for (const accbpg_dopt::MergeStage& st : h->merge_stages) {
+        if (st.kind == 0) {
+            ACC_TRY(launch_gemm_ops(h->ops + st.begin, st.end - st.begin, st.maxm, st.maxn, true, h->stream));
+        } else {
+            int gx = (int)std::min<int64_t>(1024, ((int64_t)st.maxm / 2 + 255) / 256);
+            gemm_reduce_kernel<<<dim3(gx, st.end - st.begin), 256, 0, h->stream>>>(h->red + st.begin);
+        }
     }
     prof_end(h, PROF_TRTRI);
     ACC_HIP(hipGetLastError());

@@ -36,7 +36,16 @@ struct GemmOp {
     int32_t M, N, K;
     int32_t lower_only;     // skip tiles / elements strictly above the diagonal of C
     int32_t tri;            // bit 0: B[k][col] is zero for k < col; bit 1: A[row][k] is zero for k > row (k ranges are cut)
+    int32_t koff;           // k index of this op's first k-step in the coordinates of those triangles (split-K pieces)
     double alpha, beta;
+};
+
+// sum of split-K partial products: C[r][c] = sum_p P[p*M*N + r*N + c]
+struct RedOp {
+    double* C;
+    const double* P;
+    int64_t ldc;
+    int32_t M, N, ns, pad;
 };
 
 // entry of the Gram tile list: one BM x BN tile (d1 < 0), or a pair of 128 x 128 diagonal blocks d1, d2
@@ -90,8 +99,11 @@ struct accbpg_dopt {
 
     accbpg::GemmOp* ops = nullptr;            // device op table of the inverse merges
     std::vector<accbpg::GemmOp> ops_host;
-    std::vector<int> level_begin;             // ops of level l: [level_begin[l], level_begin[l+1])
-    std::vector<int> level_maxm, level_maxn;
+    // launch list of the inverse merges: kind 0 = products ops[begin, end), kind 1 = partial-sum reductions red[begin, end)
+    struct MergeStage { int kind, begin, end, maxm, maxn; };
+    std::vector<MergeStage> merge_stages;
+    accbpg::RedOp* red = nullptr;
+    double* Pbuf = nullptr;     // m*m: split-K partial products of the top merge levels
     accbpg::GemmOp* chol_op = nullptr;        // device slot for the trailing-update op
 
     // Frank-Wolfe state
@@ -99,6 +111,7 @@ struct accbpg_dopt {
     bool fw_ready = false;
 
     bool use_glds = true;       // direct-to-LDS staging for interior big tiles (debug switch)
+    bool diag_inv_ready = false;  // the last factorisation wrote the inverses of the diagonal blocks into Wbuf
     bool has_duals = false;     // the Gram tile list holds dual diagonal tiles (direct-to-LDS kernel only)
     int chol_dbg = 0;           // timing ablation bits for chol_step_kernel (0 in production)
     bool prof_on = false;
@@ -109,7 +122,7 @@ namespace accbpg {
 
 // dopt_kernels.hip
 int launch_gram(accbpg_dopt* h, const double* x, double* gram);
-int launch_cholesky(accbpg_dopt* h, double* A /* m*m, in place */);
+int launch_cholesky(accbpg_dopt* h, double* A /* m*m, in place */, double* Winv = nullptr /* diagonal-block inverses */);
 int launch_trtri(accbpg_dopt* h);
 int launch_colnorm(accbpg_dopt* h, const double* W, double* out, double sign);
 int launch_gemm_ops(const GemmOp* ops_dev, int nops, int maxM, int maxN, bool b_kmajor, hipStream_t s);

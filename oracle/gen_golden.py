@@ -166,6 +166,24 @@ def large(accbpg, m=2048, n=32768, seed=10, iters=12):
          away_x=xa, away_F=Fa, away_SP=SPa, away_SN=SNa)
 
 
+def large_long(accbpg, m=2048, n=32768, seed=10, iters=120):
+    """Config-2 size, longer horizon: ABPG(gamma=2, theta_eq=True) and BPG with line search for `iters`
+    iterations (the two solvers whose decisions are stable to 1e-17 across BLAS thread counts; about an
+    hour of CPU on 8 cores).  Stores the final iterate, a mid-run iterate and the traces."""
+    import time
+    f, h, L, x0 = accbpg.D_opt_design(m, n, randseed=seed)
+    t = time.time()
+    half = iters // 2
+    xh, Fh, Gh, Th = accbpg.ABPG(f, h, L, x0, gamma=2.0, maxitrs=half, theta_eq=True, verbose=False)
+    x, F, G, T = accbpg.ABPG(f, h, L, x0, gamma=2.0, maxitrs=iters, theta_eq=True, verbose=False)
+    print("ABPG %d + %d its: %.1f s" % (half, iters, time.time() - t), flush=True)
+    t = time.time()
+    xb, Fb, Lb, Tb = accbpg.BPG(f, h, L, x0, maxitrs=half, linesearch=True, verbose=False)
+    print("BPG-LS %d its: %.1f s" % (half, time.time() - t), flush=True)
+    save("large_long", m=m, n=n, seed=seed, iters=iters, half=half, abpg_x=x, abpg_F=F, abpg_G=G, abpg_xh=xh,
+         bpgls_x=xb, bpgls_F=Fb, bpgls_Ls=Lb)
+
+
 def traces_512(accbpg):
     """1000-iteration traces at the config-4 instance size (about 10 minutes of CPU)."""
     f, h, L, x0 = accbpg.D_opt_design(512, 8192, randseed=10)
@@ -286,6 +304,7 @@ def main():
     ap.add_argument("--only-traces", action="store_true")
     ap.add_argument("--only-next", action="store_true")
     ap.add_argument("--only-poisson", action="store_true")
+    ap.add_argument("--only-large-long", action="store_true")
     ap.add_argument("--out", default=None, help="write into this directory instead of tests/golden")
     args = ap.parse_args()
     accbpg = load_reference()
@@ -294,6 +313,9 @@ def main():
         OUT = args.out
     if args.only_poisson:
         poisson(accbpg)
+        return
+    if args.only_large_long:
+        large_long(accbpg)
         return
     if args.only_next:
         next_rows(accbpg)
