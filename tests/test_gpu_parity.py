@@ -430,6 +430,28 @@ def test_large_abpg_gain_trajectory_2048x32768(large, acc):
     _close(F, gd["F"], 1e-9); _close(Gain, gd["Gain"], 1e-12); _close(Gdiv, gd["Gdiv"], 1e-7)
 
 
+def test_large_long_trajectories_2048x32768(large, acc):
+    """Config 2, longer horizon: 120 iterations of ABPG(gamma=2, theta_eq=True) and 60 of BPG with line
+    search against traces of the real reference (oracle/gen_golden.py --only-large-long, about 1.5 h of
+    CPU).  These are the solvers whose decisions are reproducible in the reference itself; the iterates
+    must agree to l_inf < 1e-9 at iteration 60 and at the end."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "large_long.npz")):
+        pytest.skip("tests/golden/large_long.npz not generated")
+    f, h, L, x0, _ = large
+    gd = golden("large_long")
+    iters, half = int(gd["iters"]), int(gd["half"])
+    xh, Fh, Gh, Th = acc.ABPG(f, h, L, x0, gamma=2.0, maxitrs=half, theta_eq=True, verbose=False)
+    assert np.max(np.abs(xh - gd["abpg_xh"])) < 1e-9
+    x, F, G, T = acc.ABPG(f, h, L, x0, gamma=2.0, maxitrs=iters, theta_eq=True, verbose=False)
+    assert np.max(np.abs(x - gd["abpg_x"])) < 1e-9
+    _close(F, gd["abpg_F"], 1e-9)
+    _close(G[:half], gd["abpg_G"][:half], 1e-6)
+    xb, Fb, Lb, Tb = acc.BPG(f, h, L, x0, maxitrs=half, linesearch=True, verbose=False)
+    assert np.max(np.abs(xb - gd["bpgls_x"])) < 1e-9
+    _close(Fb, gd["bpgls_F"], 1e-9); _close(Lb, gd["bpgls_Ls"], 1e-12)
+
+
 def test_large_fw_2048x32768(large, acc):
     f, h, L, x0, _ = large
     gd = golden("large_fw")
