@@ -16,17 +16,8 @@ void set_last_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-__global__ void check_nonneg_kernel(const double* __restrict__ x, int64_t n, int* __restrict__ flags) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    bool bad = false;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        if (!(x[i] >= 0.0)) bad = true;
-    if (bad) flags[FLAG_NEG_X] = 1;
-}
-
 static int read_status(accbpg_dopt* h) {
-    ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
-    ACC_HIP(hipMemcpyAsync(h->hpin + 16, h->dflag, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));
+    ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * 18, hipMemcpyDeviceToHost, h->stream));   // scalars + flags
     ACC_HIP(hipStreamSynchronize(h->stream));
     return ACCBPG_OK;
 }
@@ -64,10 +55,9 @@ extern "C" int accbpg_dopt_create(const double* V_dev, int64_t m, int64_t n, int
     ACC_HIP(hipMemset(h->Lbuf, 0, mm));
     ACC_HIP(hipMemset(h->Wbuf, 0, mm));     // the upper triangle of W must read as zero
     ACC_HIP(hipMemset(h->Tbuf, 0, mm));
-    ACC_HIP(hipMalloc(&h->dscal, sizeof(double) * 16));
-    ACC_HIP(hipMalloc(&h->dflag, sizeof(int) * 8));
-    ACC_HIP(hipMemset(h->dscal, 0, sizeof(double) * 16));
-    ACC_HIP(hipMemset(h->dflag, 0, sizeof(int) * 8));
+    ACC_HIP(hipMalloc(&h->dscal, sizeof(double) * 24));        // 16 scalars, then the status flags: one readback
+    h->dflag = reinterpret_cast<int*>(h->dscal + 16);
+    ACC_HIP(hipMemset(h->dscal, 0, sizeof(double) * 24));
     ACC_HIP(hipHostMalloc(&h->hpin, sizeof(double) * 32, hipHostMallocDefault));
     const int64_t vws = std::max<int64_t>(vec_ws_doubles(n), 64 * n);
     ACC_HIP(hipMalloc(&h->vws, sizeof(double) * (size_t)vws));
@@ -80,7 +70,7 @@ extern "C" int accbpg_dopt_create(const double* V_dev, int64_t m, int64_t n, int
 extern "C" int accbpg_dopt_destroy(accbpg_dopt* h) {
     if (!h) return ACCBPG_OK;
     hipFree(h->Lbuf); hipFree(h->Wbuf); hipFree(h->Tbuf); hipFree(h->slabs); hipFree(h->tiles); hipFree(h->wg_ranges); hipFree(h->gram_cstart); hipFree(h->gram_contrib);
-    hipFree(h->dscal); hipFree(h->dflag); hipFree(h->vws); hipFree(h->xbuf); hipFree(h->ops); hipFree(h->chol_op); hipFree(h->red); hipFree(h->Pbuf);
+    hipFree(h->dscal); hipFree(h->vws); hipFree(h->xbuf); hipFree(h->ops); hipFree(h->chol_op); hipFree(h->red); hipFree(h->Pbuf);
     hipFree(h->fw_x); hipFree(h->fw_w); hipFree(h->fw_H); hipFree(h->fw_hv);
     if (h->hpin) hipHostFree(h->hpin);
     for (auto& p : h->prof)
@@ -130,14 +120,13 @@ extern "C" int accbpg_dopt_func_grad_begin(accbpg_dopt* h, const double* x_dev, 
     if (!h || !x_dev || flag < 0 || flag > 2) return ACCBPG_ERR_ARG;
     if (flag != 0 && !g_dev) return ACCBPG_ERR_ARG;
     ACC_TRY(launch_gram(h, x_dev, h->Lbuf));
-    ACC_TRY(launch_cholesky(h, h->Lbuf, flag != 0 ? h->Wbuf : nullptr));   // resets the flags first
-    check_nonneg_kernel<<<64, 256, 0, h->stream>>>(x_dev, h->n, h->dflag);      // functions.py:45
+    // resets the scalars and flags first, and checks x >= 0 in the same launch (functions.py:45)
+    ACC_TRY(launch_cholesky(h, h->Lbuf, flag != 0 ? h->Wbuf : nullptr, x_dev));
     if (flag != 0) {
         ACC_TRY(launch_trtri(h));
         ACC_TRY(launch_colnorm(h, h->Wbuf, g_dev, -1.0));
     }
-    ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * 4, hipMemcpyDeviceToHost, h->stream));
-    ACC_HIP(hipMemcpyAsync(h->hpin + 16, h->dflag, sizeof(int) * 4, hipMemcpyDeviceToHost, h->stream));
+    ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * 18, hipMemcpyDeviceToHost, h->stream));   // scalars + flags
     return ACCBPG_OK;
 }
 

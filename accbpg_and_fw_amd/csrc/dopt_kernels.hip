@@ -1184,9 +1184,16 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(const double* __restrict
     }
 }
 
-__global__ void zero_scalars_kernel(double* dscal, int* dflag) {
+// resets the scalars and the status flags; with x != NULL also the x >= 0 check of functions.py:45
+__global__ __launch_bounds__(1024) void zero_scalars_kernel(double* dscal, int* dflag, const double* __restrict__ x,
+                                                          int64_t n) {
     if (threadIdx.x < 8) dscal[threadIdx.x] = 0.0;
-    if (threadIdx.x < 8) dflag[threadIdx.x] = 0;
+    if (threadIdx.x < 4) dflag[threadIdx.x] = 0;
+    if (x == nullptr) return;
+    bool bad = false;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
+        if (!(x[i] >= 0.0)) bad = true;
+    if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) dflag[FLAG_NEG_X] = 1;
 }
 
 __global__ void set_op_kernel(GemmOp* slot, GemmOp op) { *slot = op; }
@@ -1626,11 +1633,11 @@ int launch_gemm_ops(const GemmOp* ops_dev, int nops, int maxM, int maxN, bool b_
 
 // In-place Cholesky of the lower triangle of A (m x m, ld m).  Resets and fills dscal[0] (log det)
 // and dflag[FLAG_NOT_PD].  T = ceil(m/64) launches.
-int launch_cholesky(accbpg_dopt* h, double* A, double* Winv) {
+int launch_cholesky(accbpg_dopt* h, double* A, double* Winv, const double* xcheck) {
     const int64_t m = h->m;
     const int T = (int)((m + NB - 1) / NB);
     prof_begin(h, PROF_CHOL);
-    zero_scalars_kernel<<<1, 64, 0, h->stream>>>(h->dscal, h->dflag);
+    zero_scalars_kernel<<<1, xcheck ? 1024 : 64, 0, h->stream>>>(h->dscal, h->dflag, xcheck, h->n);
     for (int kprev = -1; kprev <= T - 2; ++kprev) {
         const int kc = kprev + 1;
         const int npanel = T - kc;

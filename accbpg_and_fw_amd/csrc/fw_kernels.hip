@@ -262,8 +262,8 @@ namespace accbpg { int vt_nsplit(int64_t m, int64_t n, int num_cu); }
 static int fw_nsplit(const accbpg_dopt* h) { return vt_nsplit(h->m, h->n, h->num_cu); }
 
 static int read_scalars(accbpg_dopt* h, int nd, int ni) {
-    ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * nd, hipMemcpyDeviceToHost, h->stream));
-    ACC_HIP(hipMemcpyAsync(h->hpin + 16, h->dflag, sizeof(int) * ni, hipMemcpyDeviceToHost, h->stream));
+    (void)nd; (void)ni;
+    ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * 18, hipMemcpyDeviceToHost, h->stream));   // scalars + flags
     ACC_HIP(hipStreamSynchronize(h->stream));
     return ACCBPG_OK;
 }

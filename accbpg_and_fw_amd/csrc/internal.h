@@ -122,7 +122,8 @@ namespace accbpg {
 
 // dopt_kernels.hip
 int launch_gram(accbpg_dopt* h, const double* x, double* gram);
-int launch_cholesky(accbpg_dopt* h, double* A /* m*m, in place */, double* Winv = nullptr /* diagonal-block inverses */);
+int launch_cholesky(accbpg_dopt* h, double* A /* m*m, in place */, double* Winv = nullptr /* diagonal-block inverses */,
+                    const double* xcheck = nullptr /* x >= 0 check folded into the reset launch */);
 int launch_trtri(accbpg_dopt* h);
 int launch_colnorm(accbpg_dopt* h, const double* W, double* out, double sign);
 int launch_gemm_ops(const GemmOp* ops_dev, int nops, int maxM, int maxN, bool b_kmajor, hipStream_t s);

@@ -143,8 +143,10 @@ __global__ __launch_bounds__(PB) void burg_prox_kernel(const double* __restrict_
     } else {
         for (int64_t i = tid; i < n; i += PB) xout[i] = 1.0 / (ggbuf[i] + c);
     }
-    if (bad) flags[FLAG_NONPOS] = 1;
+    // the status is written unconditionally (no memset in front of the launch)
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
     if (tid == 0) {
+        flags[FLAG_NOT_PD] = 0; flags[FLAG_NEG_X] = 0; flags[FLAG_NONPOS] = any_bad; flags[FLAG_BAD_G] = 0;
         info[0] = nb;
         info[1] = nn;
     }
@@ -377,14 +379,12 @@ __global__ __launch_bounds__(RB) void minmax_final_kernel(const MinMaxRec* __res
 // per host thread (instances of a batch are driven from separate threads on separate streams)
 static thread_local double* g_pin = nullptr;       // pinned host scratch (32 doubles)
 static thread_local int* g_flags = nullptr;        // device flags for the handle-free entry points
-static thread_local int* g_info = nullptr;         // device {bisection, newton}
 static thread_local double* g_out = nullptr;       // device result scalars
 
 static int ensure_scratch() {
     if (g_pin) return ACCBPG_OK;
     ACC_HIP(hipHostMalloc(&g_pin, 32 * sizeof(double), hipHostMallocDefault));
     ACC_HIP(hipMalloc(&g_flags, 8 * sizeof(int)));
-    ACC_HIP(hipMalloc(&g_info, 8 * sizeof(int)));
     ACC_HIP(hipMalloc(&g_out, 16 * sizeof(double)));
     return ACCBPG_OK;
 }
@@ -411,7 +411,7 @@ extern "C" int accbpg_burg_simplex_div_prox(const double* y_dev, const double* g
     if (!(L > 0.0)) return ACCBPG_ERR_ASSERT;                 // functions.py:270 / :340
     ACC_TRY(ensure_scratch());
     hipStream_t s = (hipStream_t)stream;
-    ACC_HIP(hipMemsetAsync(g_flags, 0, 8 * sizeof(int), s));
+    int* g_info = g_flags + 4;                                  // {bisection, newton} right behind the flags
     if (n <= (int64_t)PB * 2)
         burg_prox_kernel<2><<<1, PB, 0, s>>>(y_dev, g_dev, L, eps, n, x_out_dev, ws_dev, g_info, g_flags);
     else if (n <= (int64_t)PB * 8)
@@ -422,8 +422,7 @@ extern "C" int accbpg_burg_simplex_div_prox(const double* y_dev, const double* g
         burg_prox_kernel<0><<<1, PB, 0, s>>>(y_dev, g_dev, L, eps, n, x_out_dev, ws_dev, g_info, g_flags);
     ACC_HIP(hipGetLastError());
     int* pin_i = reinterpret_cast<int*>(g_pin);
-    ACC_HIP(hipMemcpyAsync(pin_i, g_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-    ACC_HIP(hipMemcpyAsync(pin_i + 4, g_info, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    ACC_HIP(hipMemcpyAsync(pin_i, g_flags, 6 * sizeof(int), hipMemcpyDeviceToHost, s));   // flags + info, one copy
     ACC_HIP(hipStreamSynchronize(s));
     if (info_host) { info_host[0] = pin_i[4]; info_host[1] = pin_i[5]; }
     if (pin_i[FLAG_NONPOS]) return ACCBPG_ERR_ASSERT;         // y.min() > 0, functions.py:270
