@@ -206,6 +206,36 @@ __global__ __launch_bounds__(FB) void fw_wupdate_kernel(double* __restrict__ w, 
     }
 }
 
+// The same update fused with stage 1 of the NEXT iteration's probe (fw_probe_partial_kernel): the new w
+// is in registers anyway, x was updated earlier in this step.
+__global__ __launch_bounds__(FB) void fw_wupdate_probe_kernel(double* __restrict__ w, int64_t n,
+                                                             const double* __restrict__ upart, int nsplit,
+                                                             double hcoef, double hdiv,
+                                                             const double* __restrict__ x, int away,
+                                                             ValIdx* __restrict__ part) {
+    __shared__ ValIdx sh[FB / 64];
+    const double inf = __builtin_inf();
+    const double thr = away ? 1.0e-8 : 0.0;
+    ValIdx best{-inf, INT64_MAX}, lo{inf, INT64_MAX};
+    const int64_t stride = (int64_t)gridDim.x * FB;
+    for (int64_t k = (int64_t)blockIdx.x * FB + threadIdx.x; k < n; k += stride) {
+        double u = 0.0;
+        for (int s = 0; s < nsplit; ++s) u += upart[(int64_t)s * n + k];
+        const double sq = u * u;
+        const double t = hcoef * sq;
+        const double wk = (w[k] + t) / hdiv;
+        w[k] = wk;
+        best = better_max(best, ValIdx{wk, k});
+        if (x[k] > thr) lo = better_min(lo, ValIdx{wk, k});
+    }
+    const ValIdx mx = block_reduce_vi_n<true, FB>(best, sh);
+    const ValIdx mn = block_reduce_vi_n<false, FB>(lo, sh);
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = mx;
+        part[2 * blockIdx.x + 1] = mn;
+    }
+}
+
 // u = sum of the row-split partials (u = V^T q)
 __global__ __launch_bounds__(FB) void fw_usum_kernel(const double* __restrict__ upart, int nsplit, int64_t n,
                                                     double* __restrict__ u) {
@@ -293,6 +323,7 @@ extern "C" int accbpg_fw_init(accbpg_dopt* h, const double* x0_dev, double* logd
     ACC_HIP(hipGetLastError());
     ACC_HIP(hipStreamSynchronize(h->stream));
     h->fw_ready = true;
+    h->fw_part_nblk = 0;
     return ACCBPG_OK;
 }
 
@@ -314,7 +345,13 @@ extern "C" int accbpg_fw_probe_step(accbpg_dopt* h, int away, int refresh_logdet
     if (nblk < 1) nblk = 1;
     if (nblk > 512) nblk = 512;
     ValIdx* part = reinterpret_cast<ValIdx*>(h->fw_hv + 2 * h->m);      // 2*512 records behind Hv / vp
-    fw_probe_partial_kernel<<<nblk, FB, 0, h->stream>>>(h->fw_w, h->fw_x, h->n, away, part);
+    if (h->fw_part_nblk > 0 && h->fw_part_away == (away != 0)) {
+        nblk = h->fw_part_nblk;                                 // stage 1 came with the last update of w
+    } else {
+        fw_probe_partial_kernel<<<nblk, FB, 0, h->stream>>>(h->fw_w, h->fw_x, h->n, away, part);
+    }
+    h->fw_part_nblk = 0;
+    h->fw_part_away = (away != 0);
     fw_probe_final_kernel<<<1, FB, 0, h->stream>>>(part, nblk, h->fw_w, h->fw_x, h->n, away, h->dscal + 4, iout);
     ACC_HIP(hipGetLastError());
     ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * 12, hipMemcpyDeviceToHost, h->stream));
@@ -343,9 +380,13 @@ extern "C" int accbpg_fw_update(accbpg_dopt* h, int64_t p, double xscale, double
     const int ns = fw_nsplit(h);
     dim3 vg((unsigned)((n + VG_COLS - 1) / VG_COLS), (unsigned)ns);
     fw_vgemv_partial_kernel<<<vg, FB, 0, h->stream>>>(h->V, h->ldv, m, n, h->fw_hv, ns, h->vws, h->vec_ok);
+    // w update fused with stage 1 of the next probe (same support threshold as the last probe call)
     int64_t wb = (n + FB - 1) / FB;
-    if (wb > 2048) wb = 2048;
-    fw_wupdate_kernel<<<(int)wb, FB, 0, h->stream>>>(h->fw_w, n, h->vws, ns, hcoef, hdiv);
+    if (wb > 512) wb = 512;                                     // 2*512 probe records behind Hv / vp
+    ValIdx* part = reinterpret_cast<ValIdx*>(h->fw_hv + 2 * h->m);
+    fw_wupdate_probe_kernel<<<(int)wb, FB, 0, h->stream>>>(h->fw_w, n, h->vws, ns, hcoef, hdiv, h->fw_x,
+                                                          h->fw_part_away ? 1 : 0, part);
+    h->fw_part_nblk = (int)wb;
     ACC_HIP(hipGetLastError());
     return ACCBPG_OK;
 }

@@ -109,6 +109,8 @@ struct accbpg_dopt {
     // Frank-Wolfe state
     double *fw_x = nullptr, *fw_w = nullptr, *fw_H = nullptr, *fw_hv = nullptr;
     bool fw_ready = false;
+    int fw_part_nblk = 0;       // probe stage-1 records left behind by the last w update (0: none)
+    bool fw_part_away = false;  // support threshold they were computed for
 
     bool use_glds = true;       // direct-to-LDS staging for interior big tiles (debug switch)
     bool diag_inv_ready = false;  // the last factorisation wrote the inverses of the diagonal blocks into Wbuf
