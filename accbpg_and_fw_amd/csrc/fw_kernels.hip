@@ -175,7 +175,8 @@ __global__ __launch_bounds__(FB) void fw_vgemv_partial_kernel(const double* __re
         const double* vp = V + r0 * ldv + k;
 #pragma unroll 8
         for (int64_t r = r0; r < r1; ++r) {
-            const double2 v = *reinterpret_cast<const double2*>(vp);
+            // V is streamed once per pass (512 MiB at config 3): non-temporal loads keep it out of the caches
+            const double2 v = double2{__builtin_nontemporal_load(vp), __builtin_nontemporal_load(vp + 1)};
             const double h = hv[r];
             a0 = fma(h, v.x, a0);
             a1 = fma(h, v.y, a1);

@@ -63,7 +63,10 @@ __global__ __launch_bounds__(QB) void poisson_ax_kernel(const double* __restrict
             const double2* x2 = reinterpret_cast<const double2*>(x);
 #pragma unroll 4
             for (int64_t c = sub; c < n2; c += TPR) {
-                const double2 av = a2[c], xv = x2[c];
+                // A is streamed once per pass: non-temporal loads keep it out of the caches (x stays cached)
+                const double* ap = reinterpret_cast<const double*>(a2 + c);
+                const double2 av = double2{__builtin_nontemporal_load(ap), __builtin_nontemporal_load(ap + 1)};
+                const double2 xv = x2[c];
                 s0 = fma(av.x, xv.x, s0);
                 s1 = fma(av.y, xv.y, s1);
             }
