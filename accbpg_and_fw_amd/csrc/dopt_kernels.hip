@@ -829,53 +829,85 @@ __device__ __forceinline__ void solve16_quad(const double* P, double* X, int row
     for (int t = 0; t < 4; ++t) xr[4 * t + q] = xs[t];
 }
 
-// value of lane `SRC` of each 16-lane row, in every lane of that row (DPP row_newbcast, no SGPR round trip)
+// value of lane `SRC` of each 16-lane row, in every lane of that row: one 64-bit DPP move (row_newbcast is the
+// DPP control the fp64 ALU ops of gfx90a+ accept), no SGPR or LDS round trip
 template <int SRC>
 __device__ __forceinline__ double row_bcast(double v) {
-    constexpr int ctrl = 0x150 + SRC;
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + SRC, 0xF, 0xF, true);
 }
-// two rank-1 updates of step J (columns C, C+1), skipped past column 15
+// acc += l[lane C of this row] * nl as ONE instruction: v_fmac_f64 with the row broadcast applied to its
+// first source.  hipcc keeps the broadcast and the FMA apart (three instructions with 32-bit moves, two with
+// the 64-bit move), and the 16 x 16 factorisation below is bound by its instruction count.  Inline asm is
+// opaque to the hazard recogniser: NOPS adds the two wait states a DPP read needs after a VALU write of its
+// source (first update of a step) or that a following DPP read of `acc` needs (last one).
+template <int C, int NOPS_BEFORE, int NOPS_AFTER>
+__device__ __forceinline__ void fmac_row_bcast(double& acc, double l, double nl) {
+    if constexpr (NOPS_BEFORE) asm volatile("s_nop 1");
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc)
+                 : "v"(l), "v"(nl), "n"(C));
+    if constexpr (NOPS_AFTER) asm volatile("s_nop 1");
+}
+// out = y[lane C of this row] * v as one instruction (v_mul_f64 has no DPP form on gfx950: v_fmac_f64 onto a
+// zero, same rounding)
 template <int C>
-__device__ __forceinline__ void potrf16_upd2(double (&a)[16], double l) {
-    if constexpr (C < 16) a[C] = fma(-l, row_bcast<C>(l), a[C]);
-    if constexpr (C + 1 < 16) a[C + 1] = fma(-l, row_bcast<C + 1>(l), a[C + 1]);
-    __builtin_amdgcn_sched_barrier(0);
+__device__ __forceinline__ double mul_row_bcast(double y, double v) {
+    double out = 0.0;
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(out)
+                 : "v"(y), "v"(v), "n"(C));
+    return out;
 }
-// Step J of the 16x16 factorisation: `l` holds column J of the factor (entry of this lane's row).  The
-// dependent chain of the NEXT column -- its pivot, 1/sqrt, the scaling of the column -- bounds the step
-// (about 18 cycles per dependent fp64 operation), so it is kept as short as the arithmetic allows: the
-// scaling factor is v_rsq_f64 refined by ONE Newton step (2^-26 -> about 2^-51 relative; it only scales
-// the column, the diagonal entry and the log-determinant use a correctly rounded sqrt of the pivot), and
-// this step's independent rank-1 updates are dealt out between its links.
+// rank-1 updates of the columns [C0, C1) of step J (clipped to 15)
+template <int C0, int C1>
+__device__ __forceinline__ void potrf16_updates(double (&a)[16], double l, double nl) {
+    if constexpr (C0 < C1 && C0 < 16) {
+        fmac_row_bcast<C0, 0, (C0 == 15)>(a[C0], l, nl);
+        potrf16_updates<C0 + 1, C1>(a, l, nl);
+    }
+}
+// Step J of the 16x16 factorisation: `l` holds column J of the factor (entry of this lane's row).  One
+// wavefront, in-order issue: the step is bound by its dependent chain and its instruction count, so
+//   * every rank-1 update is a single v_fmac_f64 with a DPP row broadcast;
+//   * every lane takes the reciprocal square root of ITS entry of column J+1 (only lane J+1's is the
+//     pivot's; the others are never used), so the pivot is not broadcast before the rsq and the scaled
+//     column is one v_mul_f64 with the broadcast of lane J+1's factor: six dependent operations per column;
+//   * that factor is v_rsq_f64 refined by ONE Newton step (2^-26 -> about 2^-51 relative; it only scales
+//     the column, the diagonal entry and the log-determinant use a correctly rounded sqrt of the pivot).
+// Lane r keeps its own pivot (dsv), its factor (myrs) and the smallest pivot it saw (minp).
 template <int J>
 __device__ __forceinline__ void potrf16_step(double (&a)[16], double& l, int r, int k0, int bs, double& dsv,
                                              double& myrs, double& minp) {
     a[J] = l;
     if constexpr (J + 1 < 16) {
-        a[J + 1] = fma(-l, row_bcast<J + 1>(l), a[J + 1]);           // becomes the next pivot
-        const double piv = row_bcast<J + 1>(a[J + 1]);
+        const double nl = -l;
+        fmac_row_bcast<J + 1, 1, 0>(a[J + 1], l, nl);                // lane J+1: the next pivot
+        const double p = a[J + 1];
+        // the independent updates are dealt out between the links of the dependent chain (pinned: left
+        // alone they are issued as one block in the middle of it)
+        constexpr int N = 14 - J, Q = (N + 3) / 4;                   // updates left, per gap
+        double y = __builtin_amdgcn_rsq(p);                          // (a non-positive pivot spreads NaNs; minp reports it)
+        const double h = -0.5 * p;
         __builtin_amdgcn_sched_barrier(0);
-        double y = __builtin_amdgcn_rsq(piv);                        // (a non-positive pivot spreads NaNs; minp reports it)
-        const double h = -0.5 * piv;
-        minp = fmin(minp, (k0 + J + 1 < bs) ? piv : 1.0);
-        dsv = (r == J + 1) ? piv : dsv;
-        potrf16_upd2<J + 2>(a, l);
-        potrf16_upd2<J + 4>(a, l);
+        potrf16_updates<J + 2, J + 2 + Q>(a, l, nl);
+        __builtin_amdgcn_sched_barrier(0);
         const double t = h * y;
-        potrf16_upd2<J + 6>(a, l);
-        potrf16_upd2<J + 8>(a, l);
-        const double u = fma(t, y, 1.5);
-        potrf16_upd2<J + 10>(a, l);
-        potrf16_upd2<J + 12>(a, l);
-        y = y * u;                                                   // ONE Newton step, see below
-        potrf16_upd2<J + 14>(a, l);
-        myrs = (r == J + 1) ? y : myrs;
-        l = a[J + 1] * y;
         __builtin_amdgcn_sched_barrier(0);
+        potrf16_updates<J + 2 + Q, J + 2 + 2 * Q>(a, l, nl);
+        __builtin_amdgcn_sched_barrier(0);
+        const double u = fma(t, y, 1.5);
+        __builtin_amdgcn_sched_barrier(0);
+        potrf16_updates<J + 2 + 2 * Q, J + 2 + 3 * Q>(a, l, nl);
+        __builtin_amdgcn_sched_barrier(0);
+        y = y * u;
+        __builtin_amdgcn_sched_barrier(0);
+        potrf16_updates<J + 2 + 3 * Q, 16>(a, l, nl);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool mine = (r == J + 1);
+        dsv = mine ? p : dsv;
+        myrs = mine ? y : myrs;
+        minp = (mine && (k0 + J + 1 < bs)) ? p : minp;
+        l = mul_row_bcast<J + 1>(y, p);
     }
 }
 // Blocked factorisation of the 64x64 block image S (lower, identity-padded beyond bs) into Lo, in four
@@ -916,10 +948,10 @@ __device__ __forceinline__ void potrf64_blk(double* __restrict__ S, double* __re
             double l;
             {
                 const double piv = row_bcast<0>(a[0]);
-                minp = (k0 < bs) ? piv : 1.0;
                 const double rs = rsqrt_newton(piv);
                 dsv = (r == 0) ? piv : dsv;
                 myrs = (r == 0) ? rs : myrs;
+                minp = (r == 0 && k0 < bs) ? piv : 1.0;
                 l = a[0] * rs;
             }
             potrf16_step<0>(a, l, r, k0, bs, dsv, myrs, minp);
@@ -938,7 +970,7 @@ __device__ __forceinline__ void potrf64_blk(double* __restrict__ S, double* __re
             potrf16_step<13>(a, l, r, k0, bs, dsv, myrs, minp);
             potrf16_step<14>(a, l, r, k0, bs, dsv, myrs, minp);
             potrf16_step<15>(a, l, r, k0, bs, dsv, myrs, minp);
-            const bool bad = !(minp > 0.0);
+            const bool bad = __any(!(minp > 0.0));               // some row's pivot was not positive (or NaN)
             const double dg = sqrt(dsv);
             if (lane < 16) {
 #pragma unroll
