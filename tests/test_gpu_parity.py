@@ -639,6 +639,18 @@ def test_trajectories_512x8192(acc):
     _close(F[:25], gd["gain_F"][:25], 1e-9)
 
 
+@pytest.mark.parametrize("shape", [(300, 3000), (1024, 4096)])
+def test_runs_are_bitwise_reproducible(acc, shape):
+    """Fixed reduction trees, a deterministic stream-K fix-up order and no atomics: the same solver run
+    gives the same bits every time (small-tile path and big-tile path with dual tiles)."""
+    f, h, L, x0 = acc.D_opt_design(shape[0], shape[1], randseed=21)
+    ref = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=40, verbose=False)
+    for _ in range(3):
+        again = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=40, verbose=False)
+        for p, q in zip(ref[:-1], again[:-1]):
+            np.testing.assert_array_equal(p, q)
+
+
 def test_overlapped_value_evaluation_is_identical(acc):
     """Opt-in: F[k] = f(x) on a side stream beside func_grad(y).  Same kernels on the same data, so
     the whole run is bitwise identical to the sequential one."""
