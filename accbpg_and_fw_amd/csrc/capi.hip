@@ -93,7 +93,7 @@ extern "C" int accbpg_dopt_gram(accbpg_dopt* h, const double* x_dev, double* gra
 extern "C" int accbpg_dopt_factor(accbpg_dopt* h, const double* gram_dev, double* f_host) {
     if (!h || !gram_dev) return ACCBPG_ERR_ARG;
     if (gram_dev != h->Lbuf)
-        ACC_HIP(hipMemcpyAsync(h->Lbuf, gram_dev, sizeof(double) * h->m * h->m, hipMemcpyDeviceToDevice, h->stream));
+        ACC_TRY(device_copy(h->Lbuf, gram_dev, (size_t)h->m * h->m, h->stream));
     ACC_TRY(launch_cholesky(h, h->Lbuf));
     ACC_TRY(read_status(h));
     const int* fl = reinterpret_cast<const int*>(h->hpin + 16);
@@ -187,7 +187,7 @@ extern "C" int accbpg_dopt_eval_gram(accbpg_dopt* h, const double* gram_dev, int
     if (!h || !gram_dev || flag < 0 || flag > 2) return ACCBPG_ERR_ARG;
     if (flag != 0 && !g_dev) return ACCBPG_ERR_ARG;
     if (gram_dev != h->Lbuf)
-        ACC_HIP(hipMemcpyAsync(h->Lbuf, gram_dev, sizeof(double) * h->m * h->m, hipMemcpyDeviceToDevice, h->stream));
+        ACC_TRY(device_copy(h->Lbuf, gram_dev, (size_t)h->m * h->m, h->stream));
     ACC_TRY(launch_cholesky(h, h->Lbuf, flag != 0 ? h->Wbuf : nullptr));
     if (flag != 0) {
         ACC_TRY(launch_trtri(h));

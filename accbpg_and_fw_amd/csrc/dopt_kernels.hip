@@ -840,23 +840,34 @@ __device__ __forceinline__ double row_bcast(double v) {
 // the 64-bit move), and the 16 x 16 factorisation below is bound by its instruction count.  Inline asm is
 // opaque to the hazard recogniser: NOPS adds the two wait states a DPP read needs after a VALU write of its
 // source (first update of a step) or that a following DPP read of `acc` needs (last one).
+#ifndef ACCBPG_DPP_ASM
+#define ACCBPG_DPP_ASM 1
+#endif
 template <int C, int NOPS_BEFORE, int NOPS_AFTER>
 __device__ __forceinline__ void fmac_row_bcast(double& acc, double l, double nl) {
+#if ACCBPG_DPP_ASM
     if constexpr (NOPS_BEFORE) asm volatile("s_nop 1");
     asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
                  : "+v"(acc)
                  : "v"(l), "v"(nl), "n"(C));
     if constexpr (NOPS_AFTER) asm volatile("s_nop 1");
+#else
+    acc = fma(row_bcast<C>(l), nl, acc);       // compiler-managed hazards (two instructions)
+#endif
 }
 // out = y[lane C of this row] * v as one instruction (v_mul_f64 has no DPP form on gfx950: v_fmac_f64 onto a
 // zero, same rounding)
 template <int C>
 __device__ __forceinline__ double mul_row_bcast(double y, double v) {
+#if ACCBPG_DPP_ASM
     double out = 0.0;
     asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
                  : "+v"(out)
                  : "v"(y), "v"(v), "n"(C));
     return out;
+#else
+    return fma(row_bcast<C>(y), v, 0.0);
+#endif
 }
 // rank-1 updates of the columns [C0, C1) of step J (clipped to 15)
 template <int C0, int C1>
@@ -1056,7 +1067,7 @@ __device__ __forceinline__ void trsm64_blk(double* __restrict__ Xs, const double
 __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restrict__ A, int64_t lda, int64_t m,
                                                                int kprev, int T, double* __restrict__ logdet,
                                                                int* __restrict__ flags, int dbg,
-                                                               double* __restrict__ Winv) {
+                                                               double* __restrict__ Winv, double* __restrict__ Ldiag) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* Ak = lds;                       // 64 x SQ : L(i,kprev) operand image
     double* Bk = Ak + NB * SQ;              // 64 x SQ : L(kc,kprev) (or L(j,kprev)) operand image
@@ -1141,15 +1152,21 @@ __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restri
     else { __syncthreads(); for (int e = tid; e < NB * SP; e += NTHREADS) Lo[e] = S[e]; __syncthreads(); }
     const bool bad = (*badflag != 0);
     if (diag) {
+        // The factor's diagonal block goes to Ldiag, NOT over A(kc,kc): the other panel workgroups of this
+        // launch read A(kc,kc) for their own (redundant) factorisation, and one that is dispatched late
+        // must still find the unfactored block there.
         Blk64 bl;
         bl.from_lds(Lo, SP);
-        bl.store(Akk, lda, bs, bs, true);
+        bl.store(Ldiag + (int64_t)kc * NB * lda + (int64_t)kc * NB, lda, bs, bs, true);
         double lg = (tid < bs) ? log(Lo[tid * SP + tid]) : 0.0;
         for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off);
         if ((tid & 63) == 0) red[tid >> 6] = lg;
         __syncthreads();
         if (tid == 0) {
-            *logdet += 2.0 * (red[0] + red[1] + red[2] + red[3]);
+            // consecutive launches add to one scalar from different XCDs: device-scope atomic, not a plain
+            // read-modify-write through whichever L2 the workgroup sits behind
+            __hip_atomic_fetch_add(logdet, 2.0 * (red[0] + red[1] + red[2] + red[3]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             if (bad) flags[FLAG_NOT_PD] = 1;
         }
         if (Winv != nullptr) {
@@ -1219,7 +1236,7 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(const double* __restrict
 // resets the scalars and the status flags; with x != NULL also the x >= 0 check of functions.py:45
 __global__ __launch_bounds__(1024) void zero_scalars_kernel(double* dscal, int* dflag, const double* __restrict__ x,
                                                           int64_t n) {
-    if (threadIdx.x < 8) dscal[threadIdx.x] = 0.0;
+    if (threadIdx.x < 8) __hip_atomic_store(dscal + threadIdx.x, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x < 4) dflag[threadIdx.x] = 0;
     if (x == nullptr) return;
     bool bad = false;
@@ -1635,7 +1652,7 @@ int launch_gram(accbpg_dopt* h, const double* x, double* gram) {
     if (!xal && h->has_duals) {
         // the tile list was built for the direct-to-LDS kernel, which reads x in 16-byte pieces
         if (!h->xbuf) ACC_HIP(hipMalloc(&h->xbuf, sizeof(double) * (size_t)h->n));
-        ACC_HIP(hipMemcpyAsync(h->xbuf, x, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToDevice, h->stream));
+        ACC_TRY(device_copy(h->xbuf, x, (size_t)h->n, h->stream));
         x = h->xbuf;
         xal = true;
     }
@@ -1648,6 +1665,19 @@ int launch_gram(accbpg_dopt* h, const double* x, double* gram) {
         if (interior) gram_launch_t<TileSmall<false, false>>(h, x, gram);
         else gram_launch_t<TileSmall<false, true>>(h, x, gram);
     }
+    ACC_HIP(hipGetLastError());
+    return ACCBPG_OK;
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(double* __restrict__ dst, const double* __restrict__ src, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+int device_copy(double* dst, const double* src, size_t ndoubles, hipStream_t s) {
+    if (ndoubles == 0 || dst == src) return ACCBPG_OK;
+    size_t nb = (ndoubles + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    copy_kernel<<<(unsigned)nb, 256, 0, s>>>(dst, src, ndoubles);
     ACC_HIP(hipGetLastError());
     return ACCBPG_OK;
 }
@@ -1676,7 +1706,7 @@ int launch_cholesky(accbpg_dopt* h, double* A, double* Winv, const double* xchec
         const int R = T - (kc + 1);
         const int nupd = (kprev >= 0) ? R * (R + 1) / 2 : 0;
         chol_step_kernel<<<npanel + nupd, NTHREADS, CHOL_LDS_BYTES, h->stream>>>(A, m, m, kprev, T, h->dscal,
-                                                                                 h->dflag, h->chol_dbg, Winv);
+                                                                                 h->dflag, h->chol_dbg, Winv, h->Tbuf);
     }
     h->diag_inv_ready = (Winv != nullptr);
     prof_end(h, PROF_CHOL);
@@ -1690,7 +1720,8 @@ int launch_trtri(accbpg_dopt* h) {
     const int T = (int)((m + NB - 1) / NB);
     prof_begin(h, PROF_TRTRI);
     // (the factorisation leaves the inverses of the diagonal blocks in Wbuf when it was asked to)
-    if (!h->diag_inv_ready) trtri_diag_kernel<<<T, 64, 0, h->stream>>>(h->Lbuf, m, h->Wbuf, m, m);
+    // (the diagonal blocks of the factor live in Tbuf's diagonal blocks, which the merges do not use)
+    if (!h->diag_inv_ready) trtri_diag_kernel<<<T, 64, 0, h->stream>>>(h->Tbuf, m, h->Wbuf, m, m);
     h->diag_inv_ready = false;
     for (const accbpg_dopt::MergeStage& st : h->merge_stages) {
         if (st.kind == 0) {

@@ -303,7 +303,7 @@ extern "C" int accbpg_fw_init(accbpg_dopt* h, const double* x0_dev, double* logd
     if (!h || !x0_dev) return ACCBPG_ERR_ARG;
     ACC_TRY(fw_alloc(h));
     const int64_t m = h->m;
-    ACC_HIP(hipMemcpyAsync(h->fw_x, x0_dev, sizeof(double) * h->n, hipMemcpyDeviceToDevice, h->stream));
+    ACC_TRY(device_copy(h->fw_x, x0_dev, (size_t)h->n, h->stream));
     ACC_TRY(launch_gram(h, h->fw_x, h->Lbuf));                 // D_opt_alg.py:40
     ACC_TRY(launch_cholesky(h, h->Lbuf));                      // det / inv via the Cholesky factor (:41-42)
     ACC_TRY(read_scalars(h, 1, 4));
@@ -334,7 +334,7 @@ extern "C" int accbpg_fw_probe_step(accbpg_dopt* h, int away, int refresh_logdet
     double logdet = 0.0;
     if (refresh_logdet) {
         // F[k] = log det(H) from a fresh factorisation of the maintained inverse (D_opt_alg.py:136)
-        ACC_HIP(hipMemcpyAsync(h->Lbuf, h->fw_H, sizeof(double) * m * m, hipMemcpyDeviceToDevice, h->stream));
+        ACC_TRY(device_copy(h->Lbuf, h->fw_H, (size_t)m * m, h->stream));
         ACC_TRY(launch_cholesky(h, h->Lbuf));
         ACC_TRY(read_scalars(h, 1, 4));
         logdet = h->hpin[0];
@@ -394,10 +394,10 @@ extern "C" int accbpg_fw_update(accbpg_dopt* h, int64_t p, double xscale, double
 
 extern "C" int accbpg_fw_get_state(accbpg_dopt* h, double* x_dev, double* w_dev, double* H_dev) {
     if (!h || !h->fw_ready) return ACCBPG_ERR_ARG;
-    if (x_dev) ACC_HIP(hipMemcpyAsync(x_dev, h->fw_x, sizeof(double) * h->n, hipMemcpyDeviceToDevice, h->stream));
-    if (w_dev) ACC_HIP(hipMemcpyAsync(w_dev, h->fw_w, sizeof(double) * h->n, hipMemcpyDeviceToDevice, h->stream));
+    if (x_dev) ACC_TRY(device_copy(x_dev, h->fw_x, (size_t)h->n, h->stream));
+    if (w_dev) ACC_TRY(device_copy(w_dev, h->fw_w, (size_t)h->n, h->stream));
     if (H_dev)
-        ACC_HIP(hipMemcpyAsync(H_dev, h->fw_H, sizeof(double) * h->m * h->m, hipMemcpyDeviceToDevice, h->stream));
+        ACC_TRY(device_copy(H_dev, h->fw_H, (size_t)h->m * h->m, h->stream));
     ACC_HIP(hipStreamSynchronize(h->stream));
     return ACCBPG_OK;
 }

@@ -145,6 +145,9 @@ int launch_vt_times(const double* V, int64_t ldv, int64_t m, int64_t n, const do
                     double* u, bool vec_ok, hipStream_t s);
 constexpr int VT_MAXSPLIT = 64;
 
+// device-to-device copy as a kernel on the stream (no copy-engine hand-off between producer and consumer kernels)
+int device_copy(double* dst, const double* src, size_t ndoubles, hipStream_t s);
+
 // prof helpers
 void prof_begin(accbpg_dopt* h, ProfKind k);
 void prof_end(accbpg_dopt* h, ProfKind k);

@@ -175,6 +175,6 @@ extern "C" int accbpg_poisson_func_grad(accbpg_poisson* h, const double* x_dev, 
 /* Ax of the last func_grad (length m), for callers that want the fitted intensities */
 extern "C" int accbpg_poisson_get_ax(accbpg_poisson* h, double* out_dev) {
     if (!h || !out_dev) return ACCBPG_ERR_ARG;
-    ACC_HIP(hipMemcpyAsync(out_dev, h->Ax, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToDevice, h->stream));
+    ACC_TRY(device_copy(out_dev, h->Ax, (size_t)h->m, h->stream));
     return ACCBPG_OK;
 }
