@@ -671,8 +671,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_big_kernel(GemmOp op) {
 // Launch `kprev` (= -1 .. T-2) receives block column kprev finished (L(:,kprev) in place) and
 //   * panel workgroups (one per block row i >= kc = kprev+1): bring the diagonal block
 //     D = A(kc,kc) - L(kc,kprev) L(kc,kprev)^T up to date (each redundantly: 64^3 MFMA work),
-//     factor it in LDS, then either write it back (i == kc, with its log-det share) or solve
-//     their own panel block  L(i,kc) = (A(i,kc) - L(i,kprev) L(kc,kprev)^T) L(kc,kc)^-T;
+//     factor it in LDS, then either publish it (i == kc: factor block to Ldiag -- NOT over A(kc,kc), which
+//     the other panel workgroups of the launch still read -- its log-det share, and on request its inverse)
+//     or solve their own panel block  L(i,kc) = (A(i,kc) - L(i,kprev) L(kc,kprev)^T) L(kc,kc)^-T;
 //   * update workgroups: A(i,j) -= L(i,kprev) L(j,kprev)^T for the remaining tiles j > kc.
 // Everything a launch reads was written by earlier launches, so there is no hand-off between
 // workgroups inside a launch; T launches factor the matrix.
