@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import accbpg_and_fw_amd as acc
 nbad = 0
-for rep in range(40):
+for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
+    if rep % 50 == 0: print("... rep", rep, flush=True)
     f, h, L, x0 = acc.D_opt_design(300, 3000, randseed=21)
     a = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=60, verbose=False)
     b = acc.ABPG(f, h, L, x0, gamma=2.0, maxitrs=60, theta_eq=True, restart=True, verbose=False)
