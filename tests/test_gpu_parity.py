@@ -639,6 +639,26 @@ def test_trajectories_512x8192(acc):
     _close(F[:25], gd["gain_F"][:25], 1e-9)
 
 
+def test_config5_shard_shape_properties(acc):
+    """One rank's share of BASELINE config 5 -- m = 8192, 32768 local design points (2 GiB of V, 128 block
+    columns in the Cholesky, seven merge levels, a Gram tile list of 1040 entries walked in ranges longer
+    than a tile): size-independent identities, no CPU pass.  sum_i x_i (-g_i) = m exactly, and
+    f(c x) = f(x) - m log c."""
+    m, n = 8192, 32768
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    V = torch.randn(m, n, dtype=torch.float64, device="cuda", generator=gen)
+    f = acc.DOptimalObj(V)
+    x = torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) + 0.1
+    x /= x.sum()
+    fx, g = f.func_grad(x, 2)
+    assert np.isfinite(fx)
+    assert float(-(x * g).sum()) == pytest.approx(m, rel=1e-10)
+    assert f(2.5 * x) == pytest.approx(fx - m * np.log(2.5), rel=1e-12)
+    g2 = f.gradient(2.5 * x)
+    assert float((g2 * 2.5 - g).abs().max() / g.abs().max()) < 1e-10      # gradient is (-1)-homogeneous
+    del V, f
+
+
 @pytest.mark.parametrize("shape", [(300, 3000), (1024, 4096)])
 def test_runs_are_bitwise_reproducible(acc, shape):
     """Fixed reduction trees, a deterministic stream-K fix-up order and no atomics: the same solver run
