@@ -250,6 +250,7 @@ extern "C" int accbpg_debug_chol_variant(accbpg_dopt* h, int bits) {
     h->chol_dbg = bits & 63;
     if (bits & 256) h->use_glds = false;      // bit 8: register-staged Gram / gradient kernels
     if (bits & 512) h->use_glds = true;
+    if (bits & 2048) h->chol_two_level_T = (bits >> 12) & 0xffff;         // bit 11: two-level threshold (block columns)
     return ACCBPG_OK;
 }
 

@@ -668,8 +668,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_big_kernel(GemmOp op) {
 // =========================================================================================
 // Cholesky, right-looking, block NB = 64, ONE launch per block column.
 //
-// Launch `kprev` (= -1 .. T-2) receives block column kprev finished (L(:,kprev) in place) and
-//   * panel workgroups (one per block row i >= kc = kprev+1): bring the diagonal block
+// Launch kc (= 0 .. T-1) receives block column kprev = kc - 1 finished (L(:,kprev) in place) and
+//   * panel workgroups (one per block row i >= kc): bring the diagonal block
 //     D = A(kc,kc) - L(kc,kprev) L(kc,kprev)^T up to date (each redundantly: 64^3 MFMA work),
 //     factor it in LDS, then either publish it (i == kc: factor block to Ldiag -- NOT over A(kc,kc), which
 //     the other panel workgroups of the launch still read -- its log-det share, and on request its inverse)
@@ -677,11 +677,19 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_big_kernel(GemmOp op) {
 //   * update workgroups: A(i,j) -= L(i,kprev) L(j,kprev)^T for the remaining tiles j > kc.
 // Everything a launch reads was written by earlier launches, so there is no hand-off between
 // workgroups inside a launch; T launches factor the matrix.
+//
+// From T = 64 block columns on (m > 4032) the rank-64 update of the whole trailing matrix per launch is
+// bound by HBM (the trailing matrix is read and written once per block column: 8 flop per byte), and the
+// factorisation runs in two levels: the step launches update only the CHOL_NK block columns of their outer
+// panel, and chol_syrk_kernel applies the finished panel to everything behind it in one pass (rank 256,
+// a quarter of the traffic).
 // =========================================================================================
 constexpr int SP = NB + 1;   // LDS stride of a 64x64 block image (row reads by one lane per row)
 constexpr int SQ = NB + 2;   // LDS stride of a 64x64 MFMA operand image (ds_read_b64 conflict-free)
 constexpr int CHOL_LDS_DOUBLES = 2 * NB * SQ + 2 * NB * SP + 6 * NB;
 constexpr int CHOL_LDS_BYTES = CHOL_LDS_DOUBLES * 8;
+constexpr int SYRK_LDS_BYTES = 2 * NB * SQ * 8;
+constexpr int CHOL_NK = 4;     // block columns per outer panel of the two-level scheme
 
 typedef d4 acc64_t[2][2];   // 64x64 product on 4 waves (2x2), wave tile 32x32 = 2x2 MFMA fragments
 
@@ -1065,8 +1073,13 @@ __device__ __forceinline__ void trsm64_blk(double* __restrict__ Xs, const double
     }
 }
 
+// kc: block column to factor; pend: the rank-64 update from block column kc - 1 is still owed to the
+// columns kc .. jmax (false for the first column of the matrix and, in the two-level scheme, for the first
+// column of an outer panel, which chol_syrk_kernel has brought up to date); jmax: last block column the
+// update workgroups touch (T - 1 in the one-level scheme, the end of the outer panel otherwise).
 __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restrict__ A, int64_t lda, int64_t m,
-                                                               int kprev, int T, double* __restrict__ logdet,
+                                                               int kc, int pend, int jmax, int T,
+                                                               double* __restrict__ logdet,
                                                                int* __restrict__ flags, int dbg,
                                                                double* __restrict__ Winv, double* __restrict__ Ldiag) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1078,19 +1091,28 @@ __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restri
     int* badflag = reinterpret_cast<int*>(misc);
     double* red = misc + 8;
     const int tid = threadIdx.x;
-    const int kc = kprev + 1;
+    const int kprev = pend ? kc - 1 : -1;
     const int npanel = T - kc;
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0);
-    const double* Lk = A + (int64_t)kprev * NB;     // block column kprev (unused if kprev < 0)
+    const double* Lk = A + (int64_t)(kc - 1) * NB;  // block column kc - 1 (unused unless pend)
     acc64_t acc;
 
     if ((int)blockIdx.x >= npanel) {
-        // ---- update role: tile (i, j), kc < j <= i:  A(i,j) -= L(i,kprev) L(j,kprev)^T
+        // ---- update role: tile (i, j), kc < j <= min(i, jmax):  A(i,j) -= L(i,kc-1) L(j,kc-1)^T
         const int u = blockIdx.x - npanel;
-        int ii = (int)((sqrt(8.0 * u + 1.0) - 1.0) * 0.5);
-        while ((ii + 1) * (ii + 2) / 2 <= u) ++ii;
-        while (ii * (ii + 1) / 2 > u) --ii;
-        const int jj = u - ii * (ii + 1) / 2;
+        int ii, jj;
+        if (jmax >= T - 1) {
+            // the whole trailing triangle, row by row
+            ii = (int)((sqrt(8.0 * u + 1.0) - 1.0) * 0.5);
+            while ((ii + 1) * (ii + 2) / 2 <= u) ++ii;
+            while (ii * (ii + 1) / 2 > u) --ii;
+            jj = u - ii * (ii + 1) / 2;
+        } else {
+            // the (jmax - kc) block columns left in the outer panel: a rectangle less its upper corner
+            const int J = jmax - kc;
+            ii = u / J; jj = u - ii * J;
+            if (jj > ii) return;
+        }
         const int i = kc + 1 + ii, j = kc + 1 + jj;
         const int mi = (int)min((int64_t)NB, m - (int64_t)i * NB), mj = (int)min((int64_t)NB, m - (int64_t)j * NB);
         Blk64 bi, bj, bc;
@@ -1196,6 +1218,78 @@ __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restri
     __syncthreads();
     bp.from_lds(Xs, SP);
     bp.store(Pik, lda, mi, bs, false);
+}
+
+// acc += As * Bs^T (mma64 without the reset)
+__device__ __forceinline__ void mma64_acc(acc64_t& acc, const double* __restrict__ As, const double* __restrict__ Bs) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lq = lane >> 4;
+    const double* ap = As + (16 * wm + lr) * SQ + lq;
+    const double* bp = Bs + (32 * wn + lr) * SQ + lq;
+#pragma unroll 4
+    for (int kk = 0; kk < NB / 4; ++kk) {
+        const double a0 = ap[4 * kk], a1 = ap[32 * SQ + 4 * kk];
+        const double b0 = bp[4 * kk], b1 = bp[16 * SQ + 4 * kk];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+}
+
+// Two-level Cholesky for large m (where the rank-64 trailing update of chol_step_kernel is bound by the HBM
+// traffic of the trailing matrix, read and written once per block column): the trailing matrix behind an
+// outer panel of nk block columns k0 .. k0+nk-1 takes all their updates in one pass,
+//   A(i,j) -= sum_k L(i,k) L(j,k)^T,   k0 + nk <= j <= i,
+// one workgroup per 64x64 tile; the operand blocks of the next k are requested while the current pair is
+// multiplied, the tile of A is requested first and consumed last.
+__global__ __launch_bounds__(NTHREADS, 2) void chol_syrk_kernel(double* __restrict__ A, int64_t lda, int64_t m,
+                                                               int k0, int nk, int T) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* Ak = lds;
+    double* Bk = Ak + NB * SQ;
+    double* S = Ak;                            // the tile image reuses the operand image after the last product:
+                                               // 66 KB of LDS, two workgroups per CU
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((lda & 1) == 0);
+    const int u = blockIdx.x;
+    int ii = (int)((sqrt(8.0 * u + 1.0) - 1.0) * 0.5);
+    while ((ii + 1) * (ii + 2) / 2 <= u) ++ii;
+    while (ii * (ii + 1) / 2 > u) --ii;
+    const int jj = u - ii * (ii + 1) / 2;
+    const int i = k0 + nk + ii, j = k0 + nk + jj;
+    if (i >= T) return;
+    const int mi = (int)min((int64_t)NB, m - (int64_t)i * NB), mj = (int)min((int64_t)NB, m - (int64_t)j * NB);
+    double* Cij = A + (int64_t)i * NB * lda + (int64_t)j * NB;
+    const double* Li = A + (int64_t)i * NB * lda + (int64_t)k0 * NB;
+    const double* Lj = A + (int64_t)j * NB * lda + (int64_t)k0 * NB;
+    Blk64 bi, bj, bc;
+    bc.load(Cij, lda, mi, mj, vec_ok);
+    bi.load(Li, lda, mi, NB, vec_ok);
+    bj.load(Lj, lda, mj, NB, vec_ok);
+    acc64_t acc;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int k = 0; k < nk; ++k) {
+        bi.to_lds(Ak, SQ);
+        bj.to_lds(Bk, SQ);
+        if (k + 1 < nk) {
+            bi.load(Li + (int64_t)(k + 1) * NB, lda, mi, NB, vec_ok);
+            bj.load(Lj + (int64_t)(k + 1) * NB, lda, mj, NB, vec_ok);
+        }
+        __syncthreads();
+        mma64_acc(acc, Ak, Bk);
+        __syncthreads();                       // the operand images are rewritten by the next k
+    }
+    bc.to_lds(S, SP);
+    __syncthreads();
+    sub_acc64(S, acc, mi, mj, i == j);
+    __syncthreads();
+    bc.from_lds(S, SP);
+    bc.store(Cij, lda, mi, mj, i == j);
 }
 
 // Inverse of every 64x64 diagonal block of L: thread j solves L11 w = e_j (column j of the
@@ -1561,6 +1655,7 @@ int build_plans(accbpg_dopt* h) {
     ACC_TRY(set_lds(gemm_ops_kernel<TileSmall<true>>, TileSmall<true>::LDS_BYTES));
     ACC_TRY(set_lds(gemm_ops_kernel<TileSmall<false>>, TileSmall<false>::LDS_BYTES));
     ACC_TRY(set_lds(chol_step_kernel, CHOL_LDS_BYTES));
+    ACC_TRY(set_lds(chol_syrk_kernel, SYRK_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>>, TileBig<false, false>::G_LDS_BYTES));
     ACC_TRY(set_lds(colnorm_glds_kernel<TileBig<true, false>>, TileBig<true, false>::G_LDS_BYTES + 4 * 128 * 8));
     ACC_TRY(set_lds(gemm_big_kernel<TileBig<true>>, TileBig<true>::LDS_BYTES));
@@ -1701,13 +1796,24 @@ int launch_cholesky(accbpg_dopt* h, double* A, double* Winv, const double* xchec
     const int T = (int)((m + NB - 1) / NB);
     prof_begin(h, PROF_CHOL);
     zero_scalars_kernel<<<1, xcheck ? 1024 : 64, 0, h->stream>>>(h->dscal, h->dflag, xcheck, h->n);
-    for (int kprev = -1; kprev <= T - 2; ++kprev) {
-        const int kc = kprev + 1;
-        const int npanel = T - kc;
-        const int R = T - (kc + 1);
-        const int nupd = (kprev >= 0) ? R * (R + 1) / 2 : 0;
-        chol_step_kernel<<<npanel + nupd, NTHREADS, CHOL_LDS_BYTES, h->stream>>>(A, m, m, kprev, T, h->dscal,
-                                                                                 h->dflag, h->chol_dbg, Winv, h->Tbuf);
+    // One level (every launch updates the whole trailing matrix) up to chol_two_level_T block columns; beyond,
+    // outer panels of CHOL_NK block columns: the step launches stay inside the panel, chol_syrk_kernel
+    // applies the panel to the rest in one pass.
+    const int nkp = (T >= h->chol_two_level_T) ? CHOL_NK : T;
+    for (int k0 = 0; k0 < T; k0 += nkp) {
+        const int kend = std::min(k0 + nkp, T) - 1;             // last block column of this outer panel
+        for (int kc = k0; kc <= kend; ++kc) {
+            const int pend = (kc > k0) ? 1 : 0;
+            const int npanel = T - kc;
+            const int R = T - (kc + 1);
+            int nupd = 0;
+            if (pend) nupd = (kend >= T - 1) ? R * (R + 1) / 2 : R * (kend - kc);
+            chol_step_kernel<<<npanel + nupd, NTHREADS, CHOL_LDS_BYTES, h->stream>>>(
+                A, m, m, kc, pend, kend, T, h->dscal, h->dflag, h->chol_dbg, Winv, h->Tbuf);
+        }
+        const int Rr = T - (kend + 1);
+        if (Rr > 0)
+            chol_syrk_kernel<<<Rr * (Rr + 1) / 2, NTHREADS, SYRK_LDS_BYTES, h->stream>>>(A, m, m, k0, kend - k0 + 1, T);
     }
     h->diag_inv_ready = (Winv != nullptr);
     prof_end(h, PROF_CHOL);

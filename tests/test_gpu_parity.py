@@ -82,12 +82,13 @@ def test_func_grad_matches_reference_golden(acc, O, tag):
 @pytest.mark.parametrize("shape", [(13, 506, 0), (80, 200, 10), (100, 1001, 4), (333, 777, 5),
                                    (768, 2048, 6), (1024, 4096, 8), (1000, 3000, 9), (1280, 2560, 11),
                                    (1024, 4112, 12), (2304, 4608, 13), (1536, 2080, 14), (4096, 8192, 15),
-                                   (3072, 49152, 16), (2560, 16384, 17), (1792, 57344, 18)])
+                                   (3072, 49152, 16), (2560, 16384, 17), (1792, 57344, 18), (4100, 8200, 19)])
 def test_func_grad_matches_oracle_ragged_sizes(acc, O, shape):
     """Sizes that are not tile multiples (odd n, odd m, big tile with edges); interior sizes whose
     Gram tile list holds dual diagonal tiles (even / odd count of them, short and long K ranges per
     workgroup, workgroups that walk through several whole tiles, tile-aligned unit ranges) and one with an
-    odd number of k-steps, where the list stays plain."""
+    odd number of k-steps, where the list stays plain.  From m = 4033 on the Cholesky runs its two-level
+    scheme (outer panels of four block columns); (4100, 8200) ends it with a one-column panel of four rows."""
     m, n, seed = shape
     V = gaussian_design(m, n, seed + 100)
     rng = np.random.RandomState(seed)
@@ -99,6 +100,31 @@ def test_func_grad_matches_oracle_ragged_sizes(acc, O, shape):
     fr, gr = fo.func_grad(x, 2)
     assert abs(fx - fr) < 1e-11 * max(1.0, abs(fr))
     np.testing.assert_allclose(g, gr, rtol=1e-11, atol=0)
+
+
+@pytest.mark.parametrize("shape", [(64, 256), (200, 700), (300, 900), (1100, 3000), (1984, 4000)])
+def test_two_level_cholesky_forced_at_small_sizes(acc, O, shape):
+    """The two-level Cholesky (production path from 64 block columns on) switched on at sizes the oracle
+    factors in no time: one block column, a lone outer panel, 4 + 1 block columns with a ragged last
+    one, 4*4 + 2, and a whole number of outer panels."""
+    from accbpg_and_fw_amd import _lib
+    m, n = shape
+    V = gaussian_design(m, n, m + n)
+    rng = np.random.RandomState(m)
+    x = rng.rand(n) + 0.01
+    x /= x.sum()
+    f = acc.DOptimalObj(V)
+    assert _lib.load().accbpg_debug_chol_variant(f._h, 2048 | (1 << 12)) == 0      # threshold: 1 block column
+    fx, g = f.func_grad(x, 2)
+    fr, gr = O.DOptOracle(V).func_grad(x, 2)
+    assert abs(fx - fr) < 1e-11 * max(1.0, abs(fr))
+    np.testing.assert_allclose(g, gr, rtol=1e-11, atol=0)
+    assert f(x) == fx                                                    # value-only path, same factorisation
+    # a matrix that is not positive definite is still reported from inside an outer panel
+    xz = np.zeros(n)
+    xz[: m // 2] = 2.0 / m
+    with pytest.raises(ValueError):
+        f(xz)
 
 
 def test_gram_unaligned_x_through_c_abi(acc, O):
