@@ -250,7 +250,10 @@ extern "C" int accbpg_debug_chol_variant(accbpg_dopt* h, int bits) {
     h->chol_dbg = bits & 63;
     if (bits & 256) h->use_glds = false;      // bit 8: register-staged Gram / gradient kernels
     if (bits & 512) h->use_glds = true;
-    if (bits & 2048) h->chol_two_level_T = (bits >> 12) & 0xffff;         // bit 11: two-level threshold (block columns)
+    if (bits & 2048) {                                                    // bit 11: two-level threshold (block columns)
+        h->chol_two_level_T = (bits >> 12) & 0xfff;                       // ... and, if given, the outer panel width
+        if ((bits >> 24) & 0x3f) h->chol_nk = (bits >> 24) & 0x3f;
+    }
     return ACCBPG_OK;
 }
 

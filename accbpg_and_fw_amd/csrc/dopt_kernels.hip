@@ -680,16 +680,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void gemm_big_kernel(GemmOp op) {
 //
 // From T = 64 block columns on (m > 4032) the rank-64 update of the whole trailing matrix per launch is
 // bound by HBM (the trailing matrix is read and written once per block column: 8 flop per byte), and the
-// factorisation runs in two levels: the step launches update only the CHOL_NK block columns of their outer
-// panel, and chol_syrk_kernel applies the finished panel to everything behind it in one pass (rank 256,
-// a quarter of the traffic).
+// factorisation runs in two levels: the step launches update only the eight block columns of their outer
+// panel, and chol_syrk_kernel applies the finished panel to everything behind it in one pass (rank 512,
+// an eighth of the traffic).
 // =========================================================================================
 constexpr int SP = NB + 1;   // LDS stride of a 64x64 block image (row reads by one lane per row)
 constexpr int SQ = NB + 2;   // LDS stride of a 64x64 MFMA operand image (ds_read_b64 conflict-free)
 constexpr int CHOL_LDS_DOUBLES = 2 * NB * SQ + 2 * NB * SP + 6 * NB;
 constexpr int CHOL_LDS_BYTES = CHOL_LDS_DOUBLES * 8;
 constexpr int SYRK_LDS_BYTES = 2 * NB * SQ * 8;
-constexpr int CHOL_NK = 4;     // block columns per outer panel of the two-level scheme
 
 typedef d4 acc64_t[2][2];   // 64x64 product on 4 waves (2x2), wave tile 32x32 = 2x2 MFMA fragments
 
@@ -1797,9 +1796,9 @@ int launch_cholesky(accbpg_dopt* h, double* A, double* Winv, const double* xchec
     prof_begin(h, PROF_CHOL);
     zero_scalars_kernel<<<1, xcheck ? 1024 : 64, 0, h->stream>>>(h->dscal, h->dflag, xcheck, h->n);
     // One level (every launch updates the whole trailing matrix) up to chol_two_level_T block columns; beyond,
-    // outer panels of CHOL_NK block columns: the step launches stay inside the panel, chol_syrk_kernel
+    // outer panels of chol_nk (8) block columns: the step launches stay inside the panel, chol_syrk_kernel
     // applies the panel to the rest in one pass.
-    const int nkp = (T >= h->chol_two_level_T) ? CHOL_NK : T;
+    const int nkp = (T >= h->chol_two_level_T) ? h->chol_nk : T;
     for (int k0 = 0; k0 < T; k0 += nkp) {
         const int kend = std::min(k0 + nkp, T) - 1;             // last block column of this outer panel
         for (int kc = k0; kc <= kend; ++kc) {

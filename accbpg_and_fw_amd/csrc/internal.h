@@ -115,6 +115,7 @@ struct accbpg_dopt {
     bool use_glds = true;       // direct-to-LDS staging for interior big tiles (debug switch)
     bool diag_inv_ready = false;  // the last factorisation wrote the inverses of the diagonal blocks into Wbuf
     bool has_duals = false;     // the Gram tile list holds dual diagonal tiles (direct-to-LDS kernel only)
+    int chol_nk = 8;            // block columns per outer panel of the two-level scheme
     int chol_two_level_T = 64;  // block columns from which the Cholesky runs its two-level scheme (m > 4032)
     int chol_dbg = 0;           // timing ablation bits for chol_step_kernel (0 in production)
     bool prof_on = false;

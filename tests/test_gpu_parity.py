@@ -88,7 +88,7 @@ def test_func_grad_matches_oracle_ragged_sizes(acc, O, shape):
     Gram tile list holds dual diagonal tiles (even / odd count of them, short and long K ranges per
     workgroup, workgroups that walk through several whole tiles, tile-aligned unit ranges) and one with an
     odd number of k-steps, where the list stays plain.  From m = 4033 on the Cholesky runs its two-level
-    scheme (outer panels of four block columns); (4100, 8200) ends it with a one-column panel of four rows."""
+    scheme (outer panels of eight block columns); (4100, 8200) ends it with a one-column panel of four rows."""
     m, n, seed = shape
     V = gaussian_design(m, n, seed + 100)
     rng = np.random.RandomState(seed)
@@ -102,11 +102,11 @@ def test_func_grad_matches_oracle_ragged_sizes(acc, O, shape):
     np.testing.assert_allclose(g, gr, rtol=1e-11, atol=0)
 
 
-@pytest.mark.parametrize("shape", [(64, 256), (200, 700), (300, 900), (1100, 3000), (1984, 4000)])
+@pytest.mark.parametrize("shape", [(64, 256), (300, 900), (520, 1600), (1100, 3000), (2048, 4100)])
 def test_two_level_cholesky_forced_at_small_sizes(acc, O, shape):
-    """The two-level Cholesky (production path from 64 block columns on) switched on at sizes the oracle
-    factors in no time: one block column, a lone outer panel, 4 + 1 block columns with a ragged last
-    one, 4*4 + 2, and a whole number of outer panels."""
+    """The two-level Cholesky (production path from 64 block columns on, outer panels of 8 block columns)
+    switched on at sizes the oracle factors in no time: one block column, a lone ragged outer panel,
+    8 + 1 block columns with a last one of 8 rows, 8 + 8 + 2, and a whole number of outer panels."""
     from accbpg_and_fw_amd import _lib
     m, n = shape
     V = gaussian_design(m, n, m + n)

@@ -17,7 +17,7 @@ for m, n in [(64, 256), (300, 900), (1100, 3000), (2048, 8192), (2080, 4200)]:
     f = acc.DOptimalObj(V)
     x = torch.rand(n, dtype=torch.float64, device="cuda") + 0.5
     x /= x.sum()
-    setting(f, 60000)
+    setting(f, 4000)
     f1, g1 = f.func_grad(x, 2)
     g1 = g1.clone()
     setting(f, 1)
@@ -27,17 +27,17 @@ for m, n in [(64, 256), (300, 900), (1100, 3000), (2048, 8192), (2080, 4200)]:
         float(-(x * g2).sum()) - m), flush=True)
     del f, V
 
-for m, n in [(4096, 8192), (6144, 8192), (8192, 16384), (8256, 16384)]:
+for m, n in [(3072, 8192), (4096, 8192), (6144, 8192), (8192, 16384), (8256, 16384)]:
     V = torch.randn(m, n, dtype=torch.float64, device="cuda")
     f = acc.DOptimalObj(V)
     x = torch.rand(n, dtype=torch.float64, device="cuda") + 0.5
     x /= x.sum()
-    for T in [60000, 1]:
-        setting(f, T)
+    for T, nk in [(4000, 4), (1, 2), (1, 3), (1, 4), (1, 6), (1, 8)]:
+        lib.accbpg_debug_chol_variant(f._h, 2048 | (T << 12) | (nk << 24))
         f.profile(True)
         for _ in range(4):
             fx = f(x)
         p = f.profile_read()
-        print("m %5d  %s  cholesky %.3f ms   f %.15g" % (m, "one-level" if T > 1 else "two-level",
+        print("m %5d  %s  cholesky %.3f ms   f %.15g" % (m, "one-level      " if T > 1 else "two-level nk=%d" % nk,
                                                         p["cholesky"][0] / p["cholesky"][1], fx), flush=True)
     del f, V
