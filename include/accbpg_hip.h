@@ -233,7 +233,11 @@ int accbpg_test_gemm(const double* A_dev, int64_t lda, const double* B_dev, int6
  * into scratch).  Average milliseconds per launch over `iters` launches. */
 int accbpg_debug_gram_variant(accbpg_dopt* h, const double* x_dev, int variant, int iters, double* ms_host);
 /* Timing ablation bits for the Cholesky step kernel (development aid; 0 = product behaviour):
- * 1 skip the diagonal-block factorisation, 2 skip the panel solve, 4 skip the MFMA products. */
+ * 1 skip the diagonal-block factorisation, 2 skip the panel solve, 4 skip the MFMA products; 8, 16, 32 switch
+ * off the row solves / MFMA updates / 16x16 factor inside the 64x64 factorisation.  256 / 512 select the
+ * register-staged / direct-to-LDS Gram and gradient kernels.  2048 sets the scheme of the factorisation
+ * (results agree to rounding): bits 12..23 = number of 64-wide block columns from which the two-level scheme
+ * runs (default 64), bits 24..29 = block columns per outer panel (default 8; 0 leaves it). */
 int accbpg_debug_chol_variant(accbpg_dopt* h, int bits);
 
 #ifdef __cplusplus
