@@ -405,7 +405,11 @@ extern "C" int accbpg_fw_get_state(accbpg_dopt* h, double* x_dev, double* w_dev,
 namespace accbpg {
 int vt_nsplit(int64_t m, int64_t n, int num_cu) {
     const int64_t colblocks = (n + VG_COLS - 1) / VG_COLS;
-    int64_t s = (4 * (int64_t)num_cu + colblocks - 1) / colblocks;
+    // About 0.8 workgroups per CU in total, NOT several per CU: measured on MI355X, the pass streams fastest
+    // when every CU follows one row range (config 3, 64 column blocks: 3 splits = 192 workgroups 124 us per
+    // FW step, 4 splits 130, 16 splits 143; Poisson (8192,65536), 128 column blocks: 2 splits 0.835 of the
+    // HBM peak, 8 splits 0.815, 1 split 0.76) -- fewer concurrent DRAM streams, and fewer partials to sum.
+    int64_t s = (4 * (int64_t)num_cu / 5 + colblocks / 2) / colblocks;
     if (s > VG_MAXSPLIT) s = VG_MAXSPLIT;
     if (s > m / 8) s = m / 8;
     if (s < 1) s = 1;
