@@ -26,6 +26,7 @@ struct accbpg_poisson {
 namespace accbpg {
 
 constexpr int QB = 256;
+constexpr unsigned PAX_HOLD_LDS = 60 * 1024;   // dynamic LDS that limits poisson_ax_kernel<64> to two workgroups per CU
 
 __device__ __forceinline__ double wsum(double v) {
 #pragma unroll
@@ -156,9 +157,16 @@ extern "C" int accbpg_poisson_func_grad(accbpg_poisson* h, const double* x_dev, 
     if (h->m < 8 * (int64_t)h->num_cu && h->n >= 4096)
         poisson_ax_kernel<QB><<<(unsigned)h->m, QB, 0, s>>>(h->A, h->lda, h->m, h->n, x_dev, h->b, h->Ax, h->r, h->t,
                                                            xvec);
-    else
-        poisson_ax_kernel<64><<<(unsigned)((h->m + QB / 64 - 1) / (QB / 64)), QB, 0, s>>>(
+    else {
+        // Long rows: hold the kernel to two workgroups (eight row streams) per CU by asking for 60 KiB of LDS
+        // it does not use, and let the dispatcher hand out the remaining rows as workgroups retire.  Measured
+        // at (8192,65536): 0.641 ms per pass against 0.683 with every CU filled to its wave limit (and 0.689
+        // for a grid-stride loop at the same two workgroups per CU: the dynamic hand-out is what balances
+        // the streams; four rows per wavefront sharing each piece of x: 0.667).
+        const unsigned hold = (h->n >= 32768) ? PAX_HOLD_LDS : 0;
+        poisson_ax_kernel<64><<<(unsigned)((h->m + QB / 64 - 1) / (QB / 64)), QB, hold, s>>>(
             h->A, h->lda, h->m, h->n, x_dev, h->b, h->Ax, h->r, h->t, xvec);
+    }
     if (flag != 1) poisson_fsum_kernel<<<1, 1024, 0, s>>>(h->t, h->m, h->dout);
     ACC_HIP(hipGetLastError());
     if (flag != 0)
