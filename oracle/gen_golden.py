@@ -184,6 +184,66 @@ def large_long(accbpg, m=2048, n=32768, seed=10, iters=120):
          bpgls_x=xb, bpgls_F=Fb, bpgls_Ls=Lb)
 
 
+class _CallLog:
+    """Pass-through around the reference's objective that notes, for every oracle call, its kind and the value
+    it returned, and keeps the argument of the value calls.  ABPG_gain asks for f at the accepted point twice
+    in a row (accbpg/algorithms.py:387 and then :347 of the next iteration), which is how the iterate x_k of
+    every k is recovered from one run without running the reference once per checkpoint."""
+
+    def __init__(self, f):
+        self._f = f
+        self.kinds = []
+        self.values = []
+        self.iterates = []
+        self._last = None
+
+    def __call__(self, x):
+        v = self._f(x)
+        self.kinds.append(0)
+        self.values.append(v)
+        if self._last is None or (self._last is not None and (self._last == x).all()):
+            self.iterates.append((len(self.kinds) - 1, x.copy()))
+        self._last = x.copy()
+        return v
+
+    def func_grad(self, x, flag=2):
+        out = self._f.func_grad(x, flag)
+        self.kinds.append(flag)
+        self.values.append(out[0] if flag == 2 else (out if flag == 0 else float("nan")))
+        return out
+
+    def gradient(self, x):
+        self.kinds.append(1)
+        self.values.append(float("nan"))
+        return self._f.gradient(x)
+
+
+def large_gain_long(accbpg, m=2048, n=32768, seed=10, iters=64, keep=(16, 24, 32, 40, 48, 56)):
+    """Config-2 size, the headline solver past its retry-free transient: ABPG_gain(gamma=2) for `iters` iterations
+    (accbpg/algorithms.py:295-420; the inner loop :361-390 starts to retry once G has been cut below what the
+    instance supports).  Stores the traces, the value every oracle call returned in call order (rejected trial
+    points included), the iterates x_k at the iterations in `keep` and the final iterate."""
+    import numpy as np
+    import time
+    f, h, L, x0 = accbpg.D_opt_design(m, n, randseed=seed)
+    log = _CallLog(f)
+    t = time.time()
+    xs, F, Gain, Gdiv, Gavg, T = accbpg.ABPG_gain(log, h, L, x0, gamma=2, maxitrs=iters, verbose=True)
+    print("ABPG_gain %d its: %.1f s" % (iters, time.time() - t), flush=True)
+    xk = {k: x for k, (pos, x) in enumerate(log.iterates)}
+    assert len(log.iterates) == len(F), (len(log.iterates), len(F))
+    for k in range(len(F)):
+        assert log.values[log.iterates[k][0]] == F[k]
+    out = dict(m=m, n=n, seed=seed, iters=iters, x=xs, F=F, Gain=Gain, Gdiv=Gdiv, Gavg=Gavg,
+               call_kinds=np.array(log.kinds, dtype=np.int8), call_values=np.array(log.values),
+               iter_call_pos=np.array([p for p, _ in log.iterates]), ref_seconds=T[-1],
+               keep=np.array([k for k in keep if k < len(F)]))
+    for k in keep:
+        if k < len(F):
+            out["x_%d" % k] = xk[k]
+    save("large_gain_long", **out)
+
+
 def traces_512(accbpg):
     """1000-iteration traces at the config-4 instance size (about 10 minutes of CPU)."""
     f, h, L, x0 = accbpg.D_opt_design(512, 8192, randseed=10)
@@ -305,6 +365,10 @@ def main():
     ap.add_argument("--only-next", action="store_true")
     ap.add_argument("--only-poisson", action="store_true")
     ap.add_argument("--only-large-long", action="store_true")
+    ap.add_argument("--only-large-gain-long", action="store_true")
+    ap.add_argument("--m", type=int, default=2048)
+    ap.add_argument("--n", type=int, default=32768)
+    ap.add_argument("--iters", type=int, default=64)
     ap.add_argument("--out", default=None, help="write into this directory instead of tests/golden")
     args = ap.parse_args()
     accbpg = load_reference()
@@ -316,6 +380,9 @@ def main():
         return
     if args.only_large_long:
         large_long(accbpg)
+        return
+    if args.only_large_gain_long:
+        large_gain_long(accbpg, args.m, args.n, iters=args.iters)
         return
     if args.only_next:
         next_rows(accbpg)

@@ -130,3 +130,33 @@ def test_libsvm_loader_edge_cases(tmp_path):
     p.write_text("1 -1:1\n")
     with pytest.raises(ValueError):
         acc.load_libsvm_file(str(p))
+
+
+def test_libsvm_loader_more_edges(tmp_path, capsys):
+    """Index-base switches, the n_features warning, compressed input, and which of two defects in one
+    file is reported (the first in file order, as accbpg/utils.py:22-95 meets them)."""
+    import gzip
+    import numpy as np
+    import accbpg_and_fw_amd as acc
+    p = tmp_path / "b.txt"
+    p.write_text("1 0:1 2:3\n")
+    with pytest.raises(ValueError, match="Invalid index 0"):
+        acc.load_libsvm_file(str(p), zero_based=False)
+    X, _ = acc.load_libsvm_file(str(p), zero_based=True)
+    assert X.shape == (1, 3)
+    p.write_text("2 1:1 4:3\n")
+    X, _ = acc.load_libsvm_file(str(p), n_features=2)            # one-based file, needs 4 columns
+    assert X.shape == (1, 4) and "n_features increased" in capsys.readouterr().out
+    X, _ = acc.load_libsvm_file(str(p), zero_based=True)         # forced zero-based: 5 columns
+    assert X.shape == (1, 5)
+    p.write_text("1 3:1 2:1\n1 -4:2\n")
+    with pytest.raises(ValueError, match="sorted and unique"):
+        acc.load_libsvm_file(str(p))
+    p.write_text("1 -4:2\n1 3:1 2:1\n")
+    with pytest.raises(ValueError, match="Invalid index -4"):
+        acc.load_libsvm_file(str(p))
+    q = tmp_path / "c.txt.gz"
+    with gzip.open(q, "wt") as fh:
+        fh.write("3 1:0.25 2:-1e3\n")
+    X, y = acc.load_libsvm_file(str(q), dtype=np.float32)
+    assert X.dtype == np.float32 and X.toarray().tolist() == [[0.25, -1000.0]] and y.tolist() == [3.0]
