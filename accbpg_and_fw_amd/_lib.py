@@ -33,9 +33,13 @@ _SIGS = {
     "accbpg_dopt_func_grad": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_double), _P]),
     "accbpg_dopt_func_grad_begin": (C.c_int, [_P, _P, C.c_int, _P]),
     "accbpg_dopt_func_grad_end": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "accbpg_dopt_eval_gap_ms": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),
     "accbpg_dopt_gram": (C.c_int, [_P, _P, _P]),
     "accbpg_dopt_factor": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),
     "accbpg_dopt_grad": (C.c_int, [_P, _P]),
+    "accbpg_tri_pack": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "accbpg_tri_unpack": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "accbpg_vec_count_bad": (C.c_int, [_P, C.c_int64, _P, _P]),
     "accbpg_dopt_gram_lincomb": (C.c_int, [_P, C.c_double, _P, C.c_double, _P, _P]),
     "accbpg_dopt_eval_gram": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_double), _P]),
     "accbpg_vec_workspace_doubles": (C.c_int64, [C.c_int64]),

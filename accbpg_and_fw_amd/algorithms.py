@@ -5,8 +5,11 @@ length-n and matrix work goes through libaccbpg_hip.so via the f / h objects of
 ``functions.py`` and the fused vector helpers there.
 
 ``x0`` may be a NumPy array (results come back as NumPy) or an fp64 CUDA tensor
-(results stay on the device).  ``T[k]`` is stamped after ``F[k]`` has been read back
-from the GPU, as the reference stamps it after ``F[k]`` is computed.
+(results stay on the device).  ``T[k]`` is the time at which ``F[k]`` was known on the
+host, as the reference stamps it right after computing ``F[k]``: read off the host clock
+when f(x) runs on the solver's stream, and corrected by the device-reported lead when it
+ran on the side stream beside the gradient evaluation (``DOptimalObj.overlap_values``,
+the default) -- see ``_stamp``.
 """
 from __future__ import annotations
 
@@ -45,6 +48,16 @@ def _value_begin(f, x, combo):
 def _value_end(f, pending):
     kind, payload = pending
     return f.value_wait(payload) if kind == "ticket" else payload
+
+
+def _stamp(f, pending, t_start, t_known):
+    """T[k]: seconds from the start of the run to the moment F[k] = f(x) was known, as the reference stamps
+    it right after that evaluation (accbpg/algorithms.py:135-137, 347-349).  `t_known` is the host clock when
+    the value came back on the solver's stream; a value that ran beside the gradient evaluation was known
+    earlier than the clock read that follows both by the lead the device reports."""
+    if pending[0] == "ticket":
+        return time.time() - t_start - f.value_lead_seconds()
+    return t_known - t_start
 
 
 def _drain(gen):
@@ -154,6 +167,7 @@ def ABPG_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=False,
     k = -1
     for k in range(maxitrs):
         pending = _value_begin(f, x, xcombo)                    # :135 (runs beside the gradient below)
+        t_known = time.time()
 
         z_prev, x_prev = z, x
         if theta_eq and kk > 0:                                 # :142-145
@@ -167,7 +181,7 @@ def ABPG_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=False,
         else:
             g = f.gradient(y)                                   # :148
         F[k] = _value_end(f, pending) + h.extra_Psi(x_prev)     # :136
-        T[k] = time.time() - t_start
+        T[k] = _stamp(f, pending, t_start, t_known)             # :137
         z = h.div_prox_map(z_prev, g, theta ** (gamma - 1) * L)  # :149
         x = vec_axpby(1 - theta, x, theta, z)                   # :150
         if _lin(f):
@@ -239,6 +253,7 @@ def ABPG_gain_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, G0=1,
     k = -1
     for k in range(maxitrs):
         pending = _value_begin(f, x, xcombo)                    # :347 (runs beside the first gradient below)
+        t_known = time.time()
 
         z_prev, x_prev = z, x
         G_prev, theta_prev = G, theta
@@ -260,7 +275,7 @@ def ABPG_gain_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, G0=1,
                 fy, g = f.func_grad(y)                          # :371
             if pending is not None:
                 F[k] = _value_end(f, pending) + h.extra_Psi(x_prev)   # :348
-                T[k] = time.time() - t_start
+                T[k] = _stamp(f, pending, t_start, t_known)           # :349
                 pending = None
             z = h.div_prox_map(z_prev, g, theta ** (gamma - 1) * G * L)   # :373
             x = vec_axpby(1 - theta, x_prev, theta, z)          # :374

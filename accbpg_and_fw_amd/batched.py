@@ -16,6 +16,47 @@ from concurrent.futures import ThreadPoolExecutor
 import torch
 
 
+def solve_instances(make_problem, num_instances, solver, world=1, rank=0, threads=None, concurrent=True,
+                    group=None, **solver_kwargs):
+    """BASELINE config 4 end to end: deal `num_instances` independent problems to the ranks
+    (``split_instances``: round-robin, so instances that stop early spread out), solve this rank's share
+    concurrently on its GPU, and gather every instance's result on every rank, in instance order.
+
+    make_problem(i) -> (f, h, L, x0) builds instance i (only called for the instances of this rank);
+    solver(f, h, L, x0, **solver_kwargs) is any solver of this package.  There is no data-path collective:
+    the only communication is the result gather (torch.distributed all_gather_object over the process
+    group that is already up -- RCCL ranks use their gloo/object path for this small host payload).
+    `concurrent=False` runs the share sequentially on the calling thread (no streams; what the CPU tests of
+    the dealing and gathering use with stand-in problems)."""
+    from .sharded import split_instances
+    mine = split_instances(num_instances, world, rank)
+    problems = [make_problem(i) for i in mine]
+    if concurrent:
+        results = solve_batch(problems, solver, threads=threads, **solver_kwargs)
+    else:
+        results = [solver(*prob, **solver_kwargs) for prob in problems]
+    local = {i: _to_host(res) for i, res in zip(mine, results)}
+    if world > 1:
+        import torch.distributed as dist
+        shares = [None] * world
+        dist.all_gather_object(shares, local, group=group)
+        merged = {}
+        for share in shares:
+            merged.update(share)
+    else:
+        merged = local
+    return [merged[i] for i in range(num_instances)]
+
+
+def _to_host(result):
+    """Solver results as host data (NumPy / floats) so that they can be shipped between ranks."""
+    if isinstance(result, torch.Tensor):
+        return result.detach().cpu().numpy()
+    if isinstance(result, (tuple, list)):
+        return type(result)(_to_host(r) for r in result)
+    return result
+
+
 def solve_batch(problems, solver, threads=None, **solver_kwargs):
     """Run ``solver(f, h, L, x0, **solver_kwargs)`` for every (f, h, L, x0) in `problems`
     concurrently; returns the list of results in order.  `solver` is any of BPG / ABPG /

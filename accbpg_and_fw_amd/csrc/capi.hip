@@ -29,25 +29,14 @@ using namespace accbpg;
 extern "C" int accbpg_abi_version(void) { return 1; }
 extern "C" const char* accbpg_last_error(void) { return g_err; }
 
-extern "C" int accbpg_dopt_create(const double* V_dev, int64_t m, int64_t n, int64_t ldv, void* stream,
-                                  accbpg_dopt** out, int is_shard) {
-    if (!V_dev || !out || m <= 0 || n <= 0 || ldv < n) {
-        set_last_error("accbpg_dopt_create: bad arguments (m=%lld n=%lld ldv=%lld)", (long long)m, (long long)n,
-                       (long long)ldv);
-        return ACCBPG_ERR_ARG;
-    }
-    if (!is_shard && !(m < n)) {            // DOptimalObj: need m < n   (functions.py:35)
-        set_last_error("DOptimalObj: need m < n");
-        return ACCBPG_ERR_ASSERT;
-    }
-    accbpg_dopt* h = new accbpg_dopt();
-    h->V = V_dev; h->m = m; h->n = n; h->ldv = ldv; h->stream = (hipStream_t)stream;
+static int dopt_init(accbpg_dopt* h) {
+    const int64_t m = h->m, n = h->n;
     ACC_HIP(hipGetDevice(&h->device));
     hipDeviceProp_t prop;
     ACC_HIP(hipGetDeviceProperties(&prop, h->device));
     h->num_cu = prop.multiProcessorCount;
     h->big = (m >= 768);
-    h->vec_ok = ((reinterpret_cast<uintptr_t>(V_dev) & 15) == 0) && ((ldv & 1) == 0);
+    h->vec_ok = ((reinterpret_cast<uintptr_t>(h->V) & 15) == 0) && ((h->ldv & 1) == 0);
     const size_t mm = sizeof(double) * (size_t)m * (size_t)m;
     ACC_HIP(hipMalloc(&h->Lbuf, mm));
     ACC_HIP(hipMalloc(&h->Wbuf, mm));
@@ -61,8 +50,28 @@ extern "C" int accbpg_dopt_create(const double* V_dev, int64_t m, int64_t n, int
     ACC_HIP(hipHostMalloc(&h->hpin, sizeof(double) * 32, hipHostMallocDefault));
     const int64_t vws = std::max<int64_t>(vec_ws_doubles(n), 64 * n);
     ACC_HIP(hipMalloc(&h->vws, sizeof(double) * (size_t)vws));
-    int rc = build_plans(h);
-    if (rc != ACCBPG_OK) { accbpg_dopt_destroy(h); return rc; }
+    ACC_HIP(hipEventCreate(&h->ev_done));
+    return build_plans(h);
+}
+
+extern "C" int accbpg_dopt_create(const double* V_dev, int64_t m, int64_t n, int64_t ldv, void* stream,
+                                  accbpg_dopt** out, int is_shard) {
+    if (!V_dev || !out || m <= 0 || n <= 0 || ldv < n) {
+        set_last_error("accbpg_dopt_create: bad arguments (m=%lld n=%lld ldv=%lld)", (long long)m, (long long)n,
+                       (long long)ldv);
+        return ACCBPG_ERR_ARG;
+    }
+    if (!is_shard && !(m < n)) {            // DOptimalObj: need m < n   (functions.py:35)
+        set_last_error("DOptimalObj: need m < n");
+        return ACCBPG_ERR_ASSERT;
+    }
+    accbpg_dopt* h = new accbpg_dopt();
+    h->V = V_dev; h->m = m; h->n = n; h->ldv = ldv; h->stream = (hipStream_t)stream;
+    const int rc = dopt_init(h);
+    if (rc != ACCBPG_OK) {                  // nothing of a half-built handle stays behind
+        accbpg_dopt_destroy(h);
+        return rc;
+    }
     *out = h;
     return ACCBPG_OK;
 }
@@ -73,6 +82,7 @@ extern "C" int accbpg_dopt_destroy(accbpg_dopt* h) {
     hipFree(h->dscal); hipFree(h->vws); hipFree(h->xbuf); hipFree(h->ops); hipFree(h->chol_op); hipFree(h->red); hipFree(h->Pbuf);
     hipFree(h->fw_x); hipFree(h->fw_w); hipFree(h->fw_H); hipFree(h->fw_hv);
     if (h->hpin) hipHostFree(h->hpin);
+    if (h->ev_done) hipEventDestroy(h->ev_done);
     for (auto& p : h->prof)
         for (auto e : p.ev) hipEventDestroy(e);
     delete h;
@@ -127,6 +137,28 @@ extern "C" int accbpg_dopt_func_grad_begin(accbpg_dopt* h, const double* x_dev, 
         ACC_TRY(launch_colnorm(h, h->Wbuf, g_dev, -1.0));
     }
     ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * 18, hipMemcpyDeviceToHost, h->stream));   // scalars + flags
+    ACC_HIP(hipEventRecord(h->ev_done, h->stream));            // when this evaluation's results are on the host
+    return ACCBPG_OK;
+}
+
+/* Milliseconds from the completion of `first`'s last begin/end evaluation to the completion of `second`'s
+ * (negative when `second` finished earlier).  Both must have been waited for with accbpg_dopt_func_grad_end.
+ * The solvers use it to stamp T[k] at the moment F[k] was known when f(x) ran beside the gradient evaluation. */
+extern "C" int accbpg_dopt_eval_gap_ms(accbpg_dopt* first, accbpg_dopt* second, double* ms_host) {
+    if (!first || !second || !ms_host) return ACCBPG_ERR_ARG;
+    float ms = 0.f;
+    const hipError_t e = hipEventElapsedTime(&ms, first->ev_done, second->ev_done);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        float back = 0.f;                                      // some runtimes refuse a negative span: ask the other way
+        if (hipEventElapsedTime(&back, second->ev_done, first->ev_done) != hipSuccess) {
+            (void)hipGetLastError();
+            set_last_error("accbpg_dopt_eval_gap_ms: no completed evaluation on one of the handles");
+            return ACCBPG_ERR_ARG;
+        }
+        ms = -back;
+    }
+    *ms_host = (double)ms;
     return ACCBPG_OK;
 }
 
@@ -169,6 +201,55 @@ __global__ void lincomb_kernel(double a, const double* __restrict__ G1, double b
     }
 }
 }  // namespace accbpg
+
+namespace accbpg {
+// packed[r(r+1)/2 + c] <-> G[r*m + c] for c <= r: the significant half of a Gram matrix, as one contiguous message
+__global__ __launch_bounds__(256) void tri_pack_kernel(const double* __restrict__ G, int64_t m, double* __restrict__ packed,
+                                                      int unpack, double* __restrict__ Gout) {
+    const int64_t r = blockIdx.x;
+    const int64_t base = r * (r + 1) / 2;
+    for (int64_t c = threadIdx.x; c <= r; c += 256) {
+        if (unpack) Gout[r * m + c] = packed[base + c];
+        else packed[base + c] = G[r * m + c];
+    }
+}
+// count[0] <- number of entries of x that are not >= 0 (NaN counts), as a double so that it can ride at the end of
+// a floating-point all-reduce buffer
+__global__ __launch_bounds__(1024) void count_bad_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ count) {
+    __shared__ int sh[16];
+    int c = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) c += !(x[i] >= 0.0);
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int i = 0; i < 16; ++i) t += sh[i];
+        count[0] = (double)t;
+    }
+}
+}  // namespace accbpg
+
+extern "C" int accbpg_tri_pack(const double* G_dev, int64_t m, double* packed_dev, void* stream) {
+    if (!G_dev || !packed_dev || m <= 0) return ACCBPG_ERR_ARG;
+    tri_pack_kernel<<<(unsigned)m, 256, 0, (hipStream_t)stream>>>(G_dev, m, packed_dev, 0, nullptr);
+    ACC_HIP(hipGetLastError());
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_tri_unpack(const double* packed_dev, int64_t m, double* G_dev, void* stream) {
+    if (!G_dev || !packed_dev || m <= 0) return ACCBPG_ERR_ARG;
+    tri_pack_kernel<<<(unsigned)m, 256, 0, (hipStream_t)stream>>>(nullptr, m, const_cast<double*>(packed_dev), 1, G_dev);
+    ACC_HIP(hipGetLastError());
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_vec_count_bad(const double* x_dev, int64_t n, double* count_dev, void* stream) {
+    if (!x_dev || !count_dev || n <= 0) return ACCBPG_ERR_ARG;
+    count_bad_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(x_dev, n, count_dev);
+    ACC_HIP(hipGetLastError());
+    return ACCBPG_OK;
+}
 
 /* out <- a*G1 + b*G2 over m*m doubles: the Gram matrix is linear in x, so the Gram matrix at
  * a*x1 + b*x2 is this combination of the Gram matrices at x1 and x2 (out may alias G1 or G2). */

@@ -16,12 +16,17 @@ struct ValIdx {
     int64_t i;
 };
 
-// first-index-on-ties argmax / argmin, the NumPy convention (D_opt_alg.py:59,61,145,147)
+// first-index-on-ties argmax / argmin, the NumPy convention (D_opt_alg.py:59,61,145,147); a NaN is the
+// extremum for both (np.argmax / np.argmin return the first NaN)
 __device__ __forceinline__ ValIdx better_max(ValIdx a, ValIdx b) {
-    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+    const bool an = a.v != a.v, bn = b.v != b.v;
+    const bool take = (bn && !an) || (!an && b.v > a.v) || ((b.v == a.v || (an && bn)) && b.i < a.i);
+    return take ? b : a;
 }
 __device__ __forceinline__ ValIdx better_min(ValIdx a, ValIdx b) {
-    return (b.v < a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+    const bool an = a.v != a.v, bn = b.v != b.v;
+    const bool take = (bn && !an) || (!an && b.v < a.v) || ((b.v == a.v || (an && bn)) && b.i < a.i);
+    return take ? b : a;
 }
 __device__ __forceinline__ ValIdx shfl_down_vi(ValIdx a, int off) {
     ValIdx r;
@@ -49,10 +54,10 @@ __device__ __forceinline__ ValIdx block_reduce_vi_n(ValIdx a, ValIdx* sh) {
 // Probe, stage 1 (one pass over w and x, many workgroups): per-block first-index argmax of w and
 // first-index argmin of w over the support mask (away: x > 1e-8, D_opt_alg.py:147; FW: x > 0, :60).
 //
-// Why one pass is enough for the away index j = argmin((w - w_i) * [x > 1e-8]) (:146-147): with
-// w_i the maximum, every masked entry is <= 0 and every unmasked entry is (-)0.  If some masked
-// w_k < w_i the minimum is the masked entry with the smallest w (first index on ties -- equal w give
-// equal differences); otherwise all entries are zero and NumPy's argmin returns index 0.
+// For the Frank-Wolfe variant the masked minimum of w is all that is needed (only w_j enters eps_neg).  The
+// away index j = argmin((w - w_i) * [x > 1e-8]) (:146-147) is taken on the ROUNDED differences, and two
+// masked entries with different w can round to the same difference from a much larger w_i, in which case
+// NumPy returns the first of them: stage 2 therefore evaluates that expression itself once w_i is known.
 __global__ __launch_bounds__(FB) void fw_probe_partial_kernel(const double* __restrict__ w,
                                                              const double* __restrict__ x, int64_t n, int away,
                                                              ValIdx* __restrict__ part) {
@@ -87,10 +92,21 @@ __global__ __launch_bounds__(FB) void fw_probe_final_kernel(const ValIdx* __rest
         lo = better_min(lo, part[2 * b + 1]);
     }
     const ValIdx mx = block_reduce_vi_n<true, FB>(best, sh);
-    const ValIdx mn = block_reduce_vi_n<false, FB>(lo, sh);
+    ValIdx mn = block_reduce_vi_n<false, FB>(lo, sh);
+    if (away) {
+        // d_k = (w_k - w_i) * [x_k > 1e-8] exactly as the reference forms it (one subtraction, one product with
+        // 1.0 or 0.0), first index of its minimum.  One workgroup over 2n doubles: a few microseconds at the
+        // sizes the away variant runs at, next to a factorisation of H per iteration.
+        ValIdx dm{inf, INT64_MAX};
+        for (int64_t k = threadIdx.x; k < n; k += FB) {
+            const double diff = w[k] - mx.v;
+            const double dk = diff * ((x[k] > 1.0e-8) ? 1.0 : 0.0);
+            dm = better_min(dm, ValIdx{dk, k});
+        }
+        mn = block_reduce_vi_n<false, FB>(dm, sh);
+    }
     if (threadIdx.x == 0) {
-        int64_t j = mn.i;
-        if (away && !(mn.v < mx.v)) j = 0;                 // every shifted, masked entry is zero
+        const int64_t j = mn.i;
         iout[0] = mx.i;
         iout[1] = j;
         dout[0] = mx.v;
@@ -308,7 +324,10 @@ extern "C" int accbpg_fw_init(accbpg_dopt* h, const double* x0_dev, double* logd
     ACC_TRY(launch_cholesky(h, h->Lbuf));                      // det / inv via the Cholesky factor (:41-42)
     ACC_TRY(read_scalars(h, 1, 4));
     const int* fl = reinterpret_cast<const int*>(h->hpin + 16);
-    if (fl[FLAG_NOT_PD]) return ACCBPG_ERR_NOT_PD;
+    if (fl[FLAG_NOT_PD]) {
+        set_last_error("accbpg_fw_init: V diag(x0) V^T is singular or not positive definite");
+        return ACCBPG_ERR_NOT_PD;
+    }
     if (logdet_gram_host) *logdet_gram_host = h->hpin[0];
     ACC_TRY(launch_trtri(h));                                  // W = L^-1
     ACC_TRY(launch_colnorm(h, h->Wbuf, h->fw_w, 1.0));         // w_i = |W v_i|^2 = v_i^T H v_i (:45)
@@ -368,7 +387,11 @@ extern "C" int accbpg_fw_probe_step(accbpg_dopt* h, int away, int refresh_logdet
 }
 
 extern "C" int accbpg_fw_update(accbpg_dopt* h, int64_t p, double xscale, double xadd, double hcoef, double hdiv) {
-    if (!h || !h->fw_ready || p < 0 || p >= h->n) return ACCBPG_ERR_ARG;
+    if (!h || !h->fw_ready || p < 0 || p >= h->n) {
+        set_last_error("accbpg_fw_update: no Frank-Wolfe state (call accbpg_fw_init) or pivot index %lld outside [0, n)",
+                       (long long)p);
+        return ACCBPG_ERR_ARG;
+    }
     const int64_t m = h->m, n = h->n;
     double* vp = h->fw_hv + m;
     int64_t gb = (std::max(n, m) + FB - 1) / FB;

@@ -118,6 +118,7 @@ struct accbpg_dopt {
     int chol_nk = 8;            // block columns per outer panel of the two-level scheme
     int chol_two_level_T = 64;  // block columns from which the Cholesky runs its two-level scheme (m > 4032)
     int chol_dbg = 0;           // timing ablation bits for chol_step_kernel (0 in production)
+    hipEvent_t ev_done = nullptr;   // recorded behind the result copy of every begin/end evaluation
     bool prof_on = false;
     accbpg::ProfSlot prof[accbpg::PROF_COUNT];
 };

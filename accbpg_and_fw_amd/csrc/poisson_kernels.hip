@@ -21,12 +21,12 @@ struct accbpg_poisson {
     double* upart = nullptr;   // VT_MAXSPLIT * n
     double* dout = nullptr;    // device scalar
     double* hpin = nullptr;    // pinned host scalar
+    unsigned hold_lds = 0;     // dynamic-LDS request that holds the A x kernel to two workgroups per CU
 };
 
 namespace accbpg {
 
 constexpr int QB = 256;
-constexpr unsigned PAX_HOLD_LDS = 60 * 1024;   // dynamic LDS that limits poisson_ax_kernel<64> to two workgroups per CU
 
 __device__ __forceinline__ double wsum(double v) {
 #pragma unroll
@@ -111,23 +111,40 @@ __global__ __launch_bounds__(1024) void poisson_fsum_kernel(const double* __rest
 
 using namespace accbpg;
 
+static int poisson_init(accbpg_poisson* h) {
+    ACC_HIP(hipGetDevice(&h->device));
+    hipDeviceProp_t prop;
+    ACC_HIP(hipGetDeviceProperties(&prop, h->device));
+    h->num_cu = prop.multiProcessorCount;
+    // LDS request that holds the wave-per-row A x kernel to two workgroups per CU: a little over a third of what
+    // a CU has (60 KiB of gfx950's 160 KiB), never more than one workgroup may ask for
+    const size_t per_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 65536;
+    size_t hold = per_cu * 3 / 8;
+    if (hold > prop.sharedMemPerBlock) hold = prop.sharedMemPerBlock;
+    h->hold_lds = (unsigned)(hold & ~(size_t)255);
+    h->vec_ok = ((reinterpret_cast<uintptr_t>(h->A) & 15) == 0) && ((h->lda & 1) == 0);
+    ACC_HIP(hipMalloc(&h->Ax, sizeof(double) * (size_t)h->m));
+    ACC_HIP(hipMalloc(&h->r, sizeof(double) * (size_t)h->m));
+    ACC_HIP(hipMalloc(&h->t, sizeof(double) * (size_t)h->m));
+    ACC_HIP(hipMalloc(&h->upart, sizeof(double) * (size_t)VT_MAXSPLIT * (size_t)h->n));
+    ACC_HIP(hipMalloc(&h->dout, sizeof(double) * 4));
+    ACC_HIP(hipHostMalloc(&h->hpin, sizeof(double) * 4, hipHostMallocDefault));
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_poisson_destroy(accbpg_poisson* h);
+
 extern "C" int accbpg_poisson_create(const double* A_dev, int64_t m, int64_t n, int64_t lda, const double* b_dev,
                                      void* stream, accbpg_poisson** out) {
     if (!A_dev || !b_dev || !out || m <= 0 || n <= 0 || lda < n) return ACCBPG_ERR_ARG;
     accbpg_poisson* h = new accbpg_poisson();
     h->A = A_dev; h->b = b_dev; h->m = m; h->n = n; h->lda = lda;
     h->stream = (hipStream_t)stream;
-    ACC_HIP(hipGetDevice(&h->device));
-    hipDeviceProp_t prop;
-    ACC_HIP(hipGetDeviceProperties(&prop, h->device));
-    h->num_cu = prop.multiProcessorCount;
-    h->vec_ok = ((reinterpret_cast<uintptr_t>(A_dev) & 15) == 0) && ((lda & 1) == 0);
-    ACC_HIP(hipMalloc(&h->Ax, sizeof(double) * (size_t)m));
-    ACC_HIP(hipMalloc(&h->r, sizeof(double) * (size_t)m));
-    ACC_HIP(hipMalloc(&h->t, sizeof(double) * (size_t)m));
-    ACC_HIP(hipMalloc(&h->upart, sizeof(double) * (size_t)VT_MAXSPLIT * (size_t)n));
-    ACC_HIP(hipMalloc(&h->dout, sizeof(double) * 4));
-    ACC_HIP(hipHostMalloc(&h->hpin, sizeof(double) * 4, hipHostMallocDefault));
+    const int rc = poisson_init(h);
+    if (rc != ACCBPG_OK) {                  // nothing of a half-built handle stays behind
+        accbpg_poisson_destroy(h);
+        return rc;
+    }
     *out = h;
     return ACCBPG_OK;
 }
@@ -163,7 +180,7 @@ extern "C" int accbpg_poisson_func_grad(accbpg_poisson* h, const double* x_dev, 
         // at (8192,65536): 0.641 ms per pass against 0.683 with every CU filled to its wave limit (and 0.689
         // for a grid-stride loop at the same two workgroups per CU: the dynamic hand-out is what balances
         // the streams; four rows per wavefront sharing each piece of x: 0.667).
-        const unsigned hold = (h->n >= 32768) ? PAX_HOLD_LDS : 0;
+        const unsigned hold = (h->n >= 32768) ? h->hold_lds : 0;
         poisson_ax_kernel<64><<<(unsigned)((h->m + QB / 64 - 1) / (QB / 64)), QB, hold, s>>>(
             h->A, h->lda, h->m, h->n, x_dev, h->b, h->Ax, h->r, h->t, xvec);
     }

@@ -7,6 +7,8 @@
 // This translation unit is compiled with -ffp-contract=off: the reference evaluates these
 // expressions with separate NumPy ufuncs (one rounding per operation), so no multiply-add here
 // may be fused.  Replaces accbpg/functions.py:246-271 and 336-356.
+#include <mutex>
+
 #include "internal.h"
 
 namespace accbpg {
@@ -20,9 +22,12 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     return v;
 }
+// minimum that keeps a NaN (np.min does; fmin would drop it and a NaN would slip through the reference's
+// `x.min() > 0` assertions, functions.py:252)
+__device__ __forceinline__ double min_nan(double a, double b) { return (b < a || b != b) ? b : a; }
 __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_down(v, off));
+    for (int off = 32; off > 0; off >>= 1) v = min_nan(v, __shfl_down(v, off));
     return v;
 }
 
@@ -46,7 +51,7 @@ __device__ __forceinline__ double block_min_bcast(double v, double* sh) {
     __syncthreads();
     double s = sh[0];
 #pragma unroll
-    for (int i = 1; i < PB / 64; ++i) s = fmin(s, sh[i]);
+    for (int i = 1; i < PB / 64; ++i) s = min_nan(s, sh[i]);
     return s;
 }
 
@@ -80,13 +85,13 @@ __global__ __launch_bounds__(PB) void burg_prox_kernel(const double* __restrict_
         for (int e = 0; e < EPT; ++e) {
             const int64_t i = tid + (int64_t)PB * e;
             gg[e] = (i < n) ? make_gg(i) : inf;
-            lmin = fmin(lmin, gg[e]);
+            lmin = min_nan(lmin, gg[e]);
         }
     } else {
         for (int64_t i = tid; i < n; i += PB) {
             const double v = make_gg(i);
             ggbuf[i] = v;
-            lmin = fmin(lmin, v);
+            lmin = min_nan(lmin, v);
         }
     }
     const double cmin = -block_min_bcast(lmin, sh);       // functions.py:342
@@ -176,14 +181,14 @@ __global__ __launch_bounds__(RB) void ls_terms_partial_kernel(const double* __re
             if (want_div_xy) {
                 const double r = xi / yi;
                 s1 += r - log(r) - 1.0;
-                mn = fmin(mn, fmin(xi, yi));
+                mn = min_nan(mn, min_nan(xi, yi));
             }
         }
         if (z != nullptr) {
             const double zi = z[i], wi = z1[i];
             const double r = zi / wi;
             s2 += r - log(r) - 1.0;
-            mn = fmin(mn, fmin(zi, wi));
+            mn = min_nan(mn, min_nan(zi, wi));
         }
     }
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); mn = wave_min(mn);
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(RB) void ls_terms_partial_kernel(const double* __re
     __syncthreads();
     if (threadIdx.x == 0) {
         double a = 0.0, b = 0.0, c = 0.0, d = sh[3][0];
-        for (int i = 0; i < RB / 64; ++i) { a += sh[0][i]; b += sh[1][i]; c += sh[2][i]; d = fmin(d, sh[3][i]); }
+        for (int i = 0; i < RB / 64; ++i) { a += sh[0][i]; b += sh[1][i]; c += sh[2][i]; d = min_nan(d, sh[3][i]); }
         part[blockIdx.x * 4 + 0] = a; part[blockIdx.x * 4 + 1] = b;
         part[blockIdx.x * 4 + 2] = c; part[blockIdx.x * 4 + 3] = d;
     }
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(RB) void ls_terms_final_kernel(const double* __rest
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, mn = __builtin_inf();
     for (int b = threadIdx.x; b < nblk; b += RB) {
         s0 += part[b * 4 + 0]; s1 += part[b * 4 + 1]; s2 += part[b * 4 + 2];
-        mn = fmin(mn, part[b * 4 + 3]);
+        mn = min_nan(mn, part[b * 4 + 3]);
     }
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); mn = wave_min(mn);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(RB) void ls_terms_final_kernel(const double* __rest
     __syncthreads();
     if (threadIdx.x == 0) {
         double a = 0.0, b = 0.0, c = 0.0, d = sh[3][0];
-        for (int i = 0; i < RB / 64; ++i) { a += sh[0][i]; b += sh[1][i]; c += sh[2][i]; d = fmin(d, sh[3][i]); }
+        for (int i = 0; i < RB / 64; ++i) { a += sh[0][i]; b += sh[1][i]; c += sh[2][i]; d = min_nan(d, sh[3][i]); }
         out[0] = a; out[1] = b; out[2] = c; out[3] = d;
     }
 }
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(RB) void min_sum_partial_kernel(const double* __res
     for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
         const double v = x[i];
         s += v;
-        mn = fmin(mn, v);
+        mn = min_nan(mn, v);
     }
     s = wave_sum(s); mn = wave_min(mn);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(RB) void min_sum_partial_kernel(const double* __res
     __syncthreads();
     if (threadIdx.x == 0) {
         double a = 0.0, d = sh[1][0];
-        for (int i = 0; i < RB / 64; ++i) { a += sh[0][i]; d = fmin(d, sh[1][i]); }
+        for (int i = 0; i < RB / 64; ++i) { a += sh[0][i]; d = min_nan(d, sh[1][i]); }
         part[blockIdx.x * 4 + 0] = a; part[blockIdx.x * 4 + 1] = 0.0;
         part[blockIdx.x * 4 + 2] = 0.0; part[blockIdx.x * 4 + 3] = d;
     }
@@ -330,9 +335,16 @@ struct MinMaxRec {
     int64_t imin, imax;
 };
 __device__ __forceinline__ MinMaxRec mm_merge(MinMaxRec a, MinMaxRec b) {
+    // np.argmin / np.argmax: a NaN is the extremum; among equals (or among NaNs) the first index wins
     MinMaxRec r = a;
-    if (b.vmin < a.vmin || (b.vmin == a.vmin && b.imin < a.imin)) { r.vmin = b.vmin; r.imin = b.imin; }
-    if (b.vmax > a.vmax || (b.vmax == a.vmax && b.imax < a.imax)) { r.vmax = b.vmax; r.imax = b.imax; }
+    const bool an = a.vmin != a.vmin, bn = b.vmin != b.vmin;
+    if ((bn && !an) || (!an && b.vmin < a.vmin) || ((b.vmin == a.vmin || (an && bn)) && b.imin < a.imin)) {
+        r.vmin = b.vmin; r.imin = b.imin;
+    }
+    const bool ax = a.vmax != a.vmax, bx = b.vmax != b.vmax;
+    if ((bx && !ax) || (!ax && b.vmax > a.vmax) || ((b.vmax == a.vmax || (ax && bx)) && b.imax < a.imax)) {
+        r.vmax = b.vmax; r.imax = b.imax;
+    }
     return r;
 }
 __device__ __forceinline__ MinMaxRec mm_block(MinMaxRec a, MinMaxRec* sh) {
@@ -376,16 +388,53 @@ __global__ __launch_bounds__(RB) void minmax_final_kernel(const MinMaxRec* __res
 }
 
 // -----------------------------------------------------------------------------------------
-// per host thread (instances of a batch are driven from separate threads on separate streams)
-static thread_local double* g_pin = nullptr;       // pinned host scratch (32 doubles)
-static thread_local int* g_flags = nullptr;        // device flags for the handle-free entry points
-static thread_local double* g_out = nullptr;       // device result scalars
+// Scratch of the handle-free entry points: one block per (host thread, device) -- instances of a batch are
+// driven from separate threads on separate streams, and one thread may drive several GPUs.  A block goes back
+// to a per-device pool when its thread ends and is handed to the next thread that asks, so generations of
+// worker threads do not grow the allocation; the pool itself lives as long as the process.
+struct ScratchBlock {
+    double* pin = nullptr;       // pinned host scratch (32 doubles)
+    int* flags = nullptr;        // device flags (8 ints)
+    double* out = nullptr;       // device result scalars (16 doubles)
+};
+constexpr int MAX_DEV = 64;
+static std::mutex g_pool_mu;
+static std::vector<ScratchBlock> g_pool[MAX_DEV];
+struct ThreadScratch {
+    ScratchBlock blk[MAX_DEV];
+    ~ThreadScratch() {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (int d = 0; d < MAX_DEV; ++d)
+            if (blk[d].pin) g_pool[d].push_back(blk[d]);
+    }
+};
+static thread_local ThreadScratch g_tls;
+static thread_local double* g_pin = nullptr;       // the block of the device current at the last ensure_scratch()
+static thread_local int* g_flags = nullptr;
+static thread_local double* g_out = nullptr;
 
 static int ensure_scratch() {
-    if (g_pin) return ACCBPG_OK;
-    ACC_HIP(hipHostMalloc(&g_pin, 32 * sizeof(double), hipHostMallocDefault));
-    ACC_HIP(hipMalloc(&g_flags, 8 * sizeof(int)));
-    ACC_HIP(hipMalloc(&g_out, 16 * sizeof(double)));
+    int dev = 0;
+    ACC_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEV) return ACCBPG_ERR_ARG;
+    ScratchBlock& b = g_tls.blk[dev];
+    if (!b.pin) {
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            if (!g_pool[dev].empty()) { b = g_pool[dev].back(); g_pool[dev].pop_back(); }
+        }
+        if (!b.pin) {
+            ScratchBlock nb;
+            ACC_HIP(hipHostMalloc(&nb.pin, 32 * sizeof(double), hipHostMallocDefault));
+            if (hipMalloc(&nb.flags, 8 * sizeof(int)) != hipSuccess || hipMalloc(&nb.out, 16 * sizeof(double)) != hipSuccess) {
+                hipHostFree(nb.pin); hipFree(nb.flags); hipFree(nb.out);
+                set_last_error("accbpg: out of device memory for the vector-kernel scratch");
+                return ACCBPG_ERR_HIP;
+            }
+            b = nb;
+        }
+    }
+    g_pin = b.pin; g_flags = b.flags; g_out = b.out;
     return ACCBPG_OK;
 }
 

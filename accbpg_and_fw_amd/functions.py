@@ -52,17 +52,25 @@ def _ptr(t):
 
 
 class _Workspace:
-    """Scratch for the length-n kernels, one per (host thread, device, n)."""
-    _cache = {}
+    """Scratch for the length-n kernels, one per (host thread, device, n).  Kept per thread (it goes away with
+    the thread, so generations of pool workers do not pile up) and bounded per thread: the least recently
+    used size is dropped beyond `_KEEP` entries."""
+    _local = threading.local()
+    _KEEP = 8
 
     @classmethod
     def get(cls, n, device):
-        key = (threading.get_ident(), device.index, int(n))
-        ws = cls._cache.get(key)
+        cache = getattr(cls._local, "cache", None)
+        if cache is None:
+            cache = cls._local.cache = {}
+        key = (device.index, int(n))
+        ws = cache.pop(key, None)
         if ws is None:
             size = _lib.load().accbpg_vec_workspace_doubles(int(n))
             ws = torch.empty(size, dtype=torch.float64, device=device)
-            cls._cache[key] = ws
+            while len(cache) >= cls._KEEP:
+                cache.pop(next(iter(cache)))
+        cache[key] = ws                      # most recently used last
         return ws
 
 
@@ -103,8 +111,10 @@ class DOptimalObj(RSmoothFunction):
         self._h = h
         self._lib = lib
         self.calls = {"value": 0, "grad": 0}
+        # F[k] = f(x) of the accelerated solvers runs beside the gradient evaluation (see overlap_values())
+        self._overlap = True
+        self._prof = False
         # opt-in reuse of resident Gram matrices through linearity (see linear_gram())
-        self._overlap = False
         self._lin = False
         self._gcache = []           # [(vector tensor, Gram tensor, age)], most recent last
         self._gcache_cap = 5
@@ -125,9 +135,10 @@ class DOptimalObj(RSmoothFunction):
 
     # ---- a value evaluation that runs beside other work (second handle, second stream) ----
     def overlap_values(self, enable=True):
-        """Opt-in: let the accelerated solvers run F[k] = f(x) on a side stream beside the gradient
-        evaluation at y (independent of it).  Identical kernels and results; off by default so that
-        per-kernel timings stay uncontended."""
+        """The accelerated solvers evaluate F[k] = f(x) on a side stream beside the gradient evaluation at y,
+        which does not depend on it (accbpg/algorithms.py:135/148, :347/371): the latency-bound factorisation
+        of one evaluation runs under the MFMA-bound products of the other.  Identical kernels and bit-identical
+        results; on by default, ``overlap_values(False)`` puts both evaluations on the solver's stream."""
         self._overlap = bool(enable)
         return self
 
@@ -145,6 +156,8 @@ class DOptimalObj(RSmoothFunction):
                                                   C.c_void_p(self._side.cuda_stream), C.byref(h2), 1)
             _lib.check(rc, "accbpg_dopt_create")
             self._h2 = h2
+            if self._prof:
+                self._lib.accbpg_dopt_profile_enable(self._h2, 1)
         with torch.cuda.device(self._V.device):
             self._side.wait_stream(torch.cuda.current_stream())          # x is produced on the caller's stream
             rc = self._lib.accbpg_dopt_func_grad_begin(self._h2, _ptr(x), 0, None)
@@ -158,6 +171,13 @@ class DOptimalObj(RSmoothFunction):
         _lib.check(rc, "accbpg_dopt_func_grad_end", "DOptimalObj: x needs to be nonnegative")
         self.calls["value"] += 1
         return fval.value
+
+    def value_lead_seconds(self):
+        """How long before the last evaluation on the solver's stream the last side-stream value was known
+        (0 when it was known later): what the solvers subtract so that T[k] is the moment F[k] existed."""
+        ms = C.c_double(0.0)
+        rc = self._lib.accbpg_dopt_eval_gap_ms(self._h2, self._h, C.byref(ms))
+        return max(0.0, ms.value * 1e-3) if rc == _lib.OK else 0.0
 
     @property
     def device(self):
@@ -325,16 +345,25 @@ class DOptimalObj(RSmoothFunction):
         return out.cpu().numpy()
 
     # ---- kernel-time accounting used by bench.py ----
+    def _handles(self):
+        return [h for h in (self._h, getattr(self, "_h2", None)) if h]
+
     def profile(self, enable=True):
-        self._lib.accbpg_dopt_profile_enable(self._h, 1 if enable else 0)
-        self._lib.accbpg_dopt_profile_reset(self._h)
+        """HIP-event timing of every kernel family on the stream it is launched on (both evaluation handles)."""
+        self._prof = bool(enable)
+        for h in self._handles():
+            self._lib.accbpg_dopt_profile_enable(h, 1 if enable else 0)
+            self._lib.accbpg_dopt_profile_reset(h)
 
     def profile_read(self):
         out = {}
         for idx, name in enumerate(["gram", "cholesky", "trtri", "grad", "gram_fixup"]):
-            ms, cnt = C.c_double(0.0), C.c_int64(0)
-            self._lib.accbpg_dopt_profile_read(self._h, idx, C.byref(ms), C.byref(cnt))
-            out[name] = (ms.value, cnt.value)
+            tot, num = 0.0, 0
+            for h in self._handles():
+                ms, cnt = C.c_double(0.0), C.c_int64(0)
+                self._lib.accbpg_dopt_profile_read(h, idx, C.byref(ms), C.byref(cnt))
+                tot, num = tot + ms.value, num + cnt.value
+            out[name] = (tot, num)
         return out
 
 

@@ -8,10 +8,11 @@ single-process).
 2. One large instance (BASELINE config 5): the design points (columns of V) are partitioned over
    the ranks.  ``H = sum_i x_i v_i v_i^T`` is a sum over design points, so per objective
    evaluation each rank forms the Gram contribution of its columns, ONE all-reduce (RCCL over
-   xGMI) sums the m x m matrices, every rank factors the (replicated) sum, evaluates the gradient
-   entries of its own columns, and one small all-reduce assembles the length-n gradient so that
-   the Burg prox, divergences and dots of the solver loop run redundantly on full vectors with no
-   further communication.  ``ShardedDOptimalObj`` has the f-protocol of ``DOptimalObj``
+   xGMI) sums them -- as packed lower triangles, m(m+1)/2 doubles, with the count of entries of the
+   local x that violate x >= 0 riding as one more element -- every rank factors the (replicated)
+   sum, evaluates the gradient entries of its own columns, and one all-gather of the slices
+   assembles the length-n gradient so that the Burg prox, divergences and dots of the solver loop
+   run redundantly on full vectors with no further communication.  ``ShardedDOptimalObj`` has the f-protocol of ``DOptimalObj``
    (``__call__``, ``gradient``, ``func_grad``), so BPG / ABPG / ABPG_gain run on it unchanged.
 
 The per-rank compute object is injectable (``local=``): on GPUs it is a ``DOptimalObj`` over the
@@ -40,7 +41,8 @@ def split_instances(num_instances, world, rank):
 
 
 class _DistSum:
-    """sum over ranks through torch.distributed (backend nccl = RCCL on ROCm, or gloo on CPU)."""
+    """sum over ranks through torch.distributed (backend nccl = RCCL on ROCm, or gloo on CPU);
+    ``gather(piece, out)`` concatenates equal-length pieces of all ranks into `out`."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
@@ -51,6 +53,38 @@ class _DistSum:
         self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group)
         return tensor
 
+    def gather(self, piece, out):
+        self.dist.all_gather_into_tensor(out, piece, group=self.group)
+        return out
+
+
+class _DeviceMessages:
+    """Message forms of the per-rank compute object on a GPU (libaccbpg_hip.so): triangle packing and the
+    x >= 0 violation count, all on the current stream without a host round trip."""
+
+    @staticmethod
+    def pack(gram, packed):
+        from . import _lib
+        from .functions import _ptr, _stream
+        with torch.cuda.device(gram.device):
+            _lib.check(_lib.load().accbpg_tri_pack(_ptr(gram), gram.shape[0], _ptr(packed), _stream()), "accbpg_tri_pack")
+
+    @staticmethod
+    def unpack(packed, gram):
+        from . import _lib
+        from .functions import _ptr, _stream
+        with torch.cuda.device(gram.device):
+            _lib.check(_lib.load().accbpg_tri_unpack(_ptr(packed), gram.shape[0], _ptr(gram), _stream()),
+                       "accbpg_tri_unpack")
+
+    @staticmethod
+    def count_bad(x_local, slot):
+        from . import _lib
+        from .functions import _ptr, _stream
+        with torch.cuda.device(x_local.device):
+            _lib.check(_lib.load().accbpg_vec_count_bad(_ptr(x_local), x_local.numel(), _ptr(slot), _stream()),
+                       "accbpg_vec_count_bad")
+
 
 class ShardedDOptimalObj(RSmoothFunction):
     """f(x) = -log det(V diag(x) V^T) with the columns of V partitioned over ranks.
@@ -58,16 +92,26 @@ class ShardedDOptimalObj(RSmoothFunction):
     local   : per-rank compute object over V[:, lo:hi] with the staged interface of
               ``DOptimalObj`` -- gram_into(x_local, gram), factor(gram) -> f, grad_from_factor(g_local)
     n       : total number of design points;  (lo, hi): this rank's columns
-    reduce  : callable summing a tensor over ranks in place (default: torch.distributed all-reduce)
+    reduce  : callable summing a tensor over ranks in place (default: torch.distributed all-reduce); if it
+              has a ``gather(piece, out)`` method the gradient slices are all-gathered, otherwise the
+              zero-padded gradient is summed
+    messages: pack / unpack / count_bad of the message buffer (default: the HIP kernels; the CPU tests pass
+              a NumPy stand-in)
     """
 
-    def __init__(self, local, m, n, lo, hi, device, reduce=None):
+    def __init__(self, local, m, n, lo, hi, device, reduce=None, messages=None, world=None):
         self.local = local
         self.m, self.n = int(m), int(n)
         self.lo, self.hi = int(lo), int(hi)
         self.device = device
         self.reduce = reduce if reduce is not None else _DistSum()
+        self.msg = messages if messages is not None else _DeviceMessages
         self._gram = torch.zeros(self.m, self.m, dtype=torch.float64, device=device)
+        # the one message per evaluation: packed lower triangle + the x >= 0 violation count (padded to a
+        # whole number of 16-byte pieces)
+        self._tri = self.m * (self.m + 1) // 2
+        self._msg = torch.zeros(self._tri + 2 - (self._tri & 1), dtype=torch.float64, device=device)
+        self.world = world
         self.calls = {"value": 0, "grad": 0}
         self.H = None           # the full design matrix is not resident on any single rank
 
@@ -81,17 +125,40 @@ class ShardedDOptimalObj(RSmoothFunction):
         assert x.numel() == self.n, "DOptimalObj: x.size not equal to n"
         x_local = x[self.lo:self.hi].contiguous()
         self.local.gram_into(x_local, self._gram)
-        self.reduce(self._gram)                                  # the one Gram all-reduce
+        self.msg.pack(self._gram, self._msg)
+        self.msg.count_bad(x_local, self._msg[self._tri:self._tri + 1])
+        self.reduce(self._msg)                                   # the one Gram all-reduce (packed triangle)
+        # accbpg/functions.py:45 on the whole vector: every rank sees the sum of every rank's violations
+        # and raises together, before anything is factored
+        assert float(self._msg[self._tri]) == 0.0, "DOptimalObj: x needs to be nonnegative"
+        self.msg.unpack(self._msg, self._gram)
         fval = self.local.factor(self._gram)                     # replicated Cholesky + log det
         self.calls["value" if flag == 0 else "grad"] += 1
         if flag == 0:
             return fval
-        g = torch.zeros(self.n, dtype=torch.float64, device=self.device)
         g_local = torch.empty(self.hi - self.lo, dtype=torch.float64, device=self.device)
         self.local.grad_from_factor(g_local)
-        g[self.lo:self.hi] = g_local
-        self.reduce(g)                                           # assemble the full gradient
+        g = self._assemble(g_local)
         return g if flag == 1 else (fval, g)
+
+    def _assemble(self, g_local):
+        """Full gradient on every rank from the slices: one all-gather (slices padded to the longest, which
+        is at most one entry more), or a sum of zero-padded vectors when the reducer cannot gather."""
+        world = self.world
+        if world is None or not hasattr(self.reduce, "gather"):
+            g = torch.zeros(self.n, dtype=torch.float64, device=self.device)
+            g[self.lo:self.hi] = g_local
+            return self.reduce(g)
+        width = -(-self.n // world)
+        piece = torch.zeros(width, dtype=torch.float64, device=self.device)
+        piece[:self.hi - self.lo] = g_local
+        parts = torch.empty(world * width, dtype=torch.float64, device=self.device)
+        self.reduce.gather(piece, parts)
+        g = torch.empty(self.n, dtype=torch.float64, device=self.device)
+        for r in range(world):
+            lo, hi = shard_bounds(self.n, world, r)
+            g[lo:hi] = parts[r * width:r * width + hi - lo]
+        return g
 
 
 class LogicalShards:
@@ -110,11 +177,22 @@ class LogicalShards:
     def func_grad(self, x, flag=2):
         from .functions import to_dev, from_dev
         xd, was_np = to_dev(x)
+        m = self.m
+        tri = m * (m + 1) // 2
+        msgs = []
         for (lo, hi), obj, gram in zip(self.bounds, self.objs, self.grams):
-            obj.gram_into(xd[lo:hi].contiguous(), gram)
-        total = self.grams[0].clone()
-        for gram in self.grams[1:]:
-            total += gram                                        # stands in for the all-reduce
+            piece = xd[lo:hi].contiguous()
+            obj.gram_into(piece, gram)
+            msg = torch.zeros(tri + 2 - (tri & 1), dtype=torch.float64, device=self.device)
+            _DeviceMessages.pack(gram, msg)                      # the same message a rank would send
+            _DeviceMessages.count_bad(piece, msg[tri:tri + 1])
+            msgs.append(msg)
+        summed = msgs[0]
+        for msg in msgs[1:]:
+            summed += msg                                        # stands in for the all-reduce
+        assert float(summed[tri]) == 0.0, "DOptimalObj: x needs to be nonnegative"
+        total = torch.zeros(m, m, dtype=torch.float64, device=self.device)
+        _DeviceMessages.unpack(summed, total)
         fvals = [obj.factor(total) for obj in self.objs]         # every "rank" factors the same sum
         if flag == 0:
             return fvals[0]
@@ -139,4 +217,4 @@ def make_sharded(V_local, m, n, rank, world, device=None, group=None):
     lo, hi = shard_bounds(n, world, rank)
     assert V_local.shape == (m, hi - lo), "V_local must hold this rank's columns"
     local = DOptimalObj(V_local, _shard=True)
-    return ShardedDOptimalObj(local, m, n, lo, hi, local.device, reduce=_DistSum(group))
+    return ShardedDOptimalObj(local, m, n, lo, hi, local.device, reduce=_DistSum(group), world=world)

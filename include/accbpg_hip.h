@@ -66,6 +66,12 @@ int accbpg_dopt_func_grad(accbpg_dopt* h, const double* x_dev, int flag,
 int accbpg_dopt_func_grad_begin(accbpg_dopt* h, const double* x_dev, int flag, double* g_dev);
 int accbpg_dopt_func_grad_end(accbpg_dopt* h, double* f_host);
 
+/* *ms_host <- milliseconds from the completion (results on the host) of `first`'s last begin/end evaluation to
+ * that of `second`'s; negative when `second` completed earlier.  Both evaluations must have been waited for.
+ * Lets the solver stamp T[k] (the reference stamps it right after F[k] = f(x), accbpg/algorithms.py:135-137,
+ * 347-349) at the moment f(x) was known although it ran beside the gradient evaluation. */
+int accbpg_dopt_eval_gap_ms(accbpg_dopt* first, accbpg_dopt* second, double* ms_host);
+
 /* The same computation in three stages, for design-point sharding across GPUs
  * (SURVEY.md 8(e).2): each rank forms its local Gram contribution, the caller all-reduces
  * gram_dev (m*m doubles, lower triangle significant) over RCCL, every rank factors it and
@@ -76,6 +82,15 @@ int accbpg_dopt_func_grad_end(accbpg_dopt* h, double* f_host);
 int accbpg_dopt_gram(accbpg_dopt* h, const double* x_dev, double* gram_dev);
 int accbpg_dopt_factor(accbpg_dopt* h, const double* gram_dev, double* f_host);
 int accbpg_dopt_grad(accbpg_dopt* h, double* g_dev);
+
+/* Message forms for the sharded evaluation (SURVEY.md 8(e).2, section 5 "packed triangle"): only the lower
+ * triangle of the local Gram matrix is significant, so the all-reduce carries m(m+1)/2 doubles,
+ * packed[r(r+1)/2 + c] = G[r*m + c] for c <= r; accbpg_vec_count_bad leaves the number of entries of x that
+ * violate the reference's `x.min() >= 0` (accbpg/functions.py:45; NaN counts) in count_dev[0] as a double, so
+ * that it can travel as one more element of the same message and every rank sees every rank's violations. */
+int accbpg_tri_pack(const double* G_dev, int64_t m, double* packed_dev, void* stream);
+int accbpg_tri_unpack(const double* packed_dev, int64_t m, double* G_dev, void* stream);
+int accbpg_vec_count_bad(const double* x_dev, int64_t n, double* count_dev, void* stream);
 
 /* Linearity of the Gram matrix in x (an extension with no reference counterpart; opt-in from the
  * Python side): out <- a*G1 + b*G2 is the Gram matrix at a*x1 + b*x2 when G1, G2 are those at x1, x2;
