@@ -38,9 +38,11 @@ def _value(f, x, combo=None):
 
 
 def _value_begin(f, x, combo):
-    """F[k] = f(x) does not feed the gradient evaluation at y: when the objective has overlapping
-    switched on (DOptimalObj.overlap_values) it is started on the side stream, otherwise evaluated now."""
-    if (not _lin(f)) and getattr(f, "_overlap", False) and isinstance(x, torch.Tensor) and x.is_cuda:
+    """F[k] = f(x) does not feed the gradient evaluation at y: it is started on the objective's side stream
+    (DOptimalObj.overlap_values, the default) unless that is switched off or kernel timing is on
+    (DOptimalObj.profile), in which case it is evaluated now."""
+    if (not _lin(f)) and getattr(f, "_overlap", False) and not getattr(f, "_prof", False) \
+            and isinstance(x, torch.Tensor) and x.is_cuda:
         return ("ticket", f.value_async(x))
     return ("value", _value(f, x, combo))
 

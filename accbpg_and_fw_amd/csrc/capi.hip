@@ -17,7 +17,7 @@ void set_last_error(const char* fmt, ...) {
 }
 
 static int read_status(accbpg_dopt* h) {
-    ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * 18, hipMemcpyDeviceToHost, h->stream));   // scalars + flags
+    ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * STATUS_DOUBLES, hipMemcpyDeviceToHost, h->stream));   // scalars + flags
     ACC_HIP(hipStreamSynchronize(h->stream));
     return ACCBPG_OK;
 }
@@ -81,6 +81,7 @@ extern "C" int accbpg_dopt_destroy(accbpg_dopt* h) {
     hipFree(h->Lbuf); hipFree(h->Wbuf); hipFree(h->Tbuf); hipFree(h->slabs); hipFree(h->tiles); hipFree(h->wg_ranges); hipFree(h->gram_cstart); hipFree(h->gram_contrib);
     hipFree(h->dscal); hipFree(h->vws); hipFree(h->xbuf); hipFree(h->ops); hipFree(h->chol_op); hipFree(h->red); hipFree(h->Pbuf);
     hipFree(h->fw_x); hipFree(h->fw_w); hipFree(h->fw_H); hipFree(h->fw_hv);
+    hipFree(h->chol_jobs); hipFree(h->chol_ready); hipFree(h->chol_aux); hipFree(h->Gbuf);
     if (h->hpin) hipHostFree(h->hpin);
     if (h->ev_done) hipEventDestroy(h->ev_done);
     for (auto& p : h->prof)
@@ -102,11 +103,17 @@ extern "C" int accbpg_dopt_gram(accbpg_dopt* h, const double* x_dev, double* gra
 
 extern "C" int accbpg_dopt_factor(accbpg_dopt* h, const double* gram_dev, double* f_host) {
     if (!h || !gram_dev) return ACCBPG_ERR_ARG;
-    if (gram_dev != h->Lbuf)
-        ACC_TRY(device_copy(h->Lbuf, gram_dev, (size_t)h->m * h->m, h->stream));
-    ACC_TRY(launch_cholesky(h, h->Lbuf));
+    ACC_TRY(launch_cholesky(h, h->Lbuf, nullptr, nullptr, gram_dev));
     ACC_TRY(read_status(h));
     const int* fl = reinterpret_cast<const int*>(h->hpin + 16);
+    if (fl[FLAG_ABORT]) {                    // the one-launch factorisation gave up a wait: launch per block column
+        if (gram_dev == h->Lbuf) {
+            set_last_error("accbpg_dopt_factor: in-place factorisation was abandoned; pass the Gram matrix in a buffer of its own");
+            return ACCBPG_ERR_HIP;
+        }
+        h->chol_tiles_off = true;
+        return accbpg_dopt_factor(h, gram_dev, f_host);
+    }
     if (fl[FLAG_NOT_PD]) {
         set_last_error("HXHT is singular or not positive definite");
         return ACCBPG_ERR_NOT_PD;
@@ -129,14 +136,17 @@ extern "C" int accbpg_dopt_grad(accbpg_dopt* h, double* g_dev) {
 extern "C" int accbpg_dopt_func_grad_begin(accbpg_dopt* h, const double* x_dev, int flag, double* g_dev) {
     if (!h || !x_dev || flag < 0 || flag > 2) return ACCBPG_ERR_ARG;
     if (flag != 0 && !g_dev) return ACCBPG_ERR_ARG;
-    ACC_TRY(launch_gram(h, x_dev, h->Lbuf));
+    h->last_x = x_dev; h->last_flag = flag; h->last_g = g_dev;
+    // (with the one-launch Cholesky the Gram matrix gets a buffer of its own and stays intact for a redo)
+    double* gram = chol_tiles_usable(h) ? h->Gbuf : h->Lbuf;
+    ACC_TRY(launch_gram(h, x_dev, gram));
     // resets the scalars and flags first, and checks x >= 0 in the same launch (functions.py:45)
-    ACC_TRY(launch_cholesky(h, h->Lbuf, flag != 0 ? h->Wbuf : nullptr, x_dev));
+    ACC_TRY(launch_cholesky(h, h->Lbuf, flag != 0 ? h->Wbuf : nullptr, x_dev, gram));
     if (flag != 0) {
         ACC_TRY(launch_trtri(h));
         ACC_TRY(launch_colnorm(h, h->Wbuf, g_dev, -1.0));
     }
-    ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * 18, hipMemcpyDeviceToHost, h->stream));   // scalars + flags
+    ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * STATUS_DOUBLES, hipMemcpyDeviceToHost, h->stream));   // scalars + flags
     ACC_HIP(hipEventRecord(h->ev_done, h->stream));            // when this evaluation's results are on the host
     return ACCBPG_OK;
 }
@@ -166,6 +176,13 @@ extern "C" int accbpg_dopt_func_grad_end(accbpg_dopt* h, double* f_host) {
     if (!h) return ACCBPG_ERR_ARG;
     ACC_HIP(hipStreamSynchronize(h->stream));
     const int* fl = reinterpret_cast<const int*>(h->hpin + 16);
+    if (fl[FLAG_ABORT] && !h->chol_tiles_off) {
+        // the one-launch factorisation gave up a wait (its workgroups were not all resident in time, e.g. another
+        // process shares the GPU): redo this evaluation with one launch per block column, and stay with that
+        h->chol_tiles_off = true;
+        ACC_TRY(accbpg_dopt_func_grad_begin(h, h->last_x, h->last_flag, h->last_g));
+        return accbpg_dopt_func_grad_end(h, f_host);
+    }
     if (fl[FLAG_NEG_X]) {
         set_last_error("DOptimalObj: x needs to be nonnegative");
         return ACCBPG_ERR_ASSERT;
@@ -267,15 +284,21 @@ extern "C" int accbpg_dopt_gram_lincomb(accbpg_dopt* h, double a, const double* 
 extern "C" int accbpg_dopt_eval_gram(accbpg_dopt* h, const double* gram_dev, int flag, double* f_host, double* g_dev) {
     if (!h || !gram_dev || flag < 0 || flag > 2) return ACCBPG_ERR_ARG;
     if (flag != 0 && !g_dev) return ACCBPG_ERR_ARG;
-    if (gram_dev != h->Lbuf)
-        ACC_TRY(device_copy(h->Lbuf, gram_dev, (size_t)h->m * h->m, h->stream));
-    ACC_TRY(launch_cholesky(h, h->Lbuf, flag != 0 ? h->Wbuf : nullptr));
+    ACC_TRY(launch_cholesky(h, h->Lbuf, flag != 0 ? h->Wbuf : nullptr, nullptr, gram_dev));
     if (flag != 0) {
         ACC_TRY(launch_trtri(h));
         ACC_TRY(launch_colnorm(h, h->Wbuf, g_dev, -1.0));
     }
     ACC_TRY(read_status(h));
     const int* fl = reinterpret_cast<const int*>(h->hpin + 16);
+    if (fl[FLAG_ABORT]) {
+        if (gram_dev == h->Lbuf) {
+            set_last_error("accbpg_dopt_eval_gram: in-place factorisation was abandoned; pass the Gram matrix in a buffer of its own");
+            return ACCBPG_ERR_HIP;
+        }
+        h->chol_tiles_off = true;
+        return accbpg_dopt_eval_gram(h, gram_dev, flag, f_host, g_dev);
+    }
     if (fl[FLAG_NOT_PD]) {
         set_last_error("HXHT is singular or not positive definite");
         return ACCBPG_ERR_NOT_PD;
@@ -329,6 +352,10 @@ extern "C" int accbpg_test_gemm(const double* A_dev, int64_t lda, const double* 
 extern "C" int accbpg_debug_chol_variant(accbpg_dopt* h, int bits) {
     if (!h) return ACCBPG_ERR_ARG;
     h->chol_dbg = bits & 63;
+    h->chol_tiles_off = (bits & 64) != 0;       // bit 6: launch-per-block-column Cholesky instead of the one-launch kernel
+    if (bits & 2048) h->chol_tiles_off = true;   // a forced scheme of the launch-per-column kernels
+    h->chol_stall_test = (bits & 128) ? 1 : 0;  // bit 7: make the one-launch kernel time out (exercises the redo); short limit
+    h->chol_spin_limit = (bits & 128) ? 200000 : 20000000;
     if (bits & 256) h->use_glds = false;      // bit 8: register-staged Gram / gradient kernels
     if (bits & 512) h->use_glds = true;
     if (bits & 2048) {                                                    // bit 11: two-level threshold (block columns)

@@ -7,6 +7,7 @@
 //   :48  np.linalg.slogdet           -> Cholesky (potrf_diag / trsm_panel / trailing GEMM), logdet = 2*sum log L_ii
 //   :57  np.linalg.solve(HXHT, H)    -> W = L^-1 (trtri_diag + merge GEMMs), Y = W V never stored
 //   :58  -sum(H * HXHTinvH, axis=0)  -> -colsum(Y*Y) fused into the product (colnorm_kernel)
+#include <mutex>
 #include <type_traits>
 
 #include "internal.h"
@@ -1291,6 +1292,285 @@ __global__ __launch_bounds__(NTHREADS, 2) void chol_syrk_kernel(double* __restri
     bc.store(Cij, lda, mi, mj, i == j);
 }
 
+// =========================================================================================
+// Cholesky in ONE launch for T <= 32 block columns (m <= 2048): every 64x64 tile of the lower triangle has an
+// OWNER workgroup that keeps it in registers (MFMA accumulator layout) from the start of the launch until the
+// tile is final, applies the rank-64 updates of the block columns to its left as their panels are published,
+// then finishes the tile (panel solve, or factorisation for a diagonal tile) and publishes it for the tiles
+// that need it.  The trailing matrix never goes back to memory between block columns, and nothing waits for a
+// whole block column: a tile moves as soon as ITS operands exist.
+//
+//   owner of diagonal tile (d,d): also owns (d,d-1).  Critical chain per block column:
+//        L(d-1,d-1) published -> [hand-off] -> solve (d,d-1) -> subtract its square from (d,d) -> factor (d,d)
+//   every other tile (i,j), i > j+1, has a workgroup of its own.
+//
+// Same arithmetic in the same order as chol_step_kernel (every update is a 64-deep product formed from zero
+// and subtracted; the same potrf64_blk / trsm64_blk), so the factor, the log-determinant and the diagonal-block
+// inverses are BIT-IDENTICAL to the launch-per-block-column scheme (test_tile_cholesky_matches_step_kernels).
+//
+// Hand-off between workgroups inside the launch (MI355X_MICROARCH.md, visibility table, first row; Guideline
+// 16 form with sc1 loads): the payload is stored write-through (agent-scope relaxed atomic stores = sc1), every
+// storing wave drains its stores, the workgroup meets at a barrier and ONE lane sets the tile's flag (agent-scope
+// store); a consumer polls that ONE word from one wave (relaxed agent-scope loads, s_sleep between polls), the
+// workgroup meets at a barrier, then EVERY load of handed-off bytes is an agent-scope (sc1) load into registers.
+// All workgroups must be resident at once (2 per CU: 76.8 KB of LDS each, <= 256 VGPRs): the host checks the
+// grid against the occupancy the runtime reports, serialises these launches across streams of the process, and
+// every spin is bounded: a wait that outlasts `spin_limit` ticks of the 100 MHz wall clock raises
+// flags[FLAG_ABORT], every workgroup leaves at its next wait, and the host redoes the factorisation with the
+// launch-per-column kernels (the source matrix is intact unless the factorisation ran in place, in which case
+// the caller regenerates it).
+// =========================================================================================
+constexpr int CT_TMAX = 32;                       // block columns this scheme handles
+constexpr int CT_AUX = 4 * POTRF_TB + 8;          // per block column: the four 16x16 factor copies + reciprocals, running log det, bad-pivot mark
+constexpr int CT_LDS_DOUBLES = 2 * NB * SQ + 4 * POTRF_TB + 16;
+constexpr int CT_LDS_BYTES = CT_LDS_DOUBLES * 8;  // 76.9 KB: two workgroups per CU
+
+struct CholJob { int i, j; };                     // i == j: owner of the diagonal tile (and of (i, i-1))
+struct CholInst {                                  // one factorisation (one entry per instance of a batched launch)
+    const double* src;      // matrix to factor (lower triangle significant), leading dimension ld
+    double* L;              // off-diagonal tiles of the factor (may be src: in place)
+    double* Ldiag;          // diagonal tiles of the factor
+    double* Winv;           // inverses of the diagonal tiles (or null)
+    double* logdet;         // scalar result
+    int* flags;             // status flags (FLAG_NOT_PD, FLAG_ABORT)
+    int* ready;             // T*T hand-off flags, zero at launch
+    double* aux;            // T * CT_AUX doubles
+};
+
+// Every shared word is accessed as a GLOBAL agent-scope access (global_load / global_store ... sc1), never through
+// a flat pointer: the pointers arrive inside a struct, which hides their address space from the compiler.
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) int gint;
+__device__ __forceinline__ double ct_ld(const double* p) {
+    return __hip_atomic_load((const gdouble*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ct_st(double* p, double v) {
+    __hip_atomic_store((gdouble*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ct_ldi(const int* p) {
+    return __hip_atomic_load((const gint*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ct_sti(int* p, int v) {
+    __hip_atomic_store((gint*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one wave, uniformly: wait until *flag != 0; false on abort / timeout
+__device__ __forceinline__ bool ct_spin(const int* flag, int* abortw, long long limit) {
+    if (ct_ldi(flag) != 0) return true;
+    const long long t0 = wall_clock64();
+    unsigned n = 0;
+    for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        if (ct_ldi(flag) != 0) return true;
+        if ((++n & 15u) == 0u) {
+            if (ct_ldi(abortw) != 0) return false;
+            if (wall_clock64() - t0 > limit) {
+                ct_sti(abortw, 1);
+                return false;
+            }
+        }
+    }
+}
+// whole workgroup: wave 0 polls the (one or two) flags, everybody learns the outcome at a barrier
+__device__ __forceinline__ bool ct_wait(const int* f0, const int* f1, int* abortw, long long limit, int* word) {
+    if (threadIdx.x < 64) {
+        bool ok = ct_spin(f0, abortw, limit);
+        if (ok && f1 != nullptr) ok = ct_spin(f1, abortw, limit);
+        if (threadIdx.x == 0) *word = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return *word != 0;
+}
+// published 64x64 block (row-major, ld) -> LDS image with row stride ST; rows >= mr / columns >= mc read as zero;
+// LOWER: entries above the diagonal read as zero too (a diagonal tile of the factor is stored lower-only)
+template <int ST, bool LOWER>
+__device__ __forceinline__ void ct_fetch(double* __restrict__ img, const double* G, int64_t ld, int mr, int mc) {
+    const int tid = threadIdx.x;
+    const int c = 2 * (tid & 31), r0 = tid >> 5;
+    double v[16];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int r = r0 + 8 * p;
+        const bool in0 = r < mr && c < mc && (!LOWER || c <= r);
+        const bool in1 = r < mr && c + 1 < mc && (!LOWER || c + 1 <= r);
+        v[2 * p] = in0 ? ct_ld(G + (int64_t)r * ld + c) : 0.0;
+        v[2 * p + 1] = in1 ? ct_ld(G + (int64_t)r * ld + c + 1) : 0.0;
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        img[(r0 + 8 * p) * ST + c] = v[2 * p];
+        img[(r0 + 8 * p) * ST + c + 1] = v[2 * p + 1];
+    }
+}
+// LDS image (stride SP) -> global, write-through; the caller drains and flags
+template <bool LOWER>
+__device__ __forceinline__ void ct_publish(const double* __restrict__ img, double* G, int64_t ld, int mr, int mc) {
+    const int tid = threadIdx.x;
+    const int c = 2 * (tid & 31), r0 = tid >> 5;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int r = r0 + 8 * p;
+        if (r < mr) {
+            if (c < mc && (!LOWER || c <= r)) ct_st(G + (int64_t)r * ld + c, img[r * SP + c]);
+            if (c + 1 < mc && (!LOWER || c + 1 <= r)) ct_st(G + (int64_t)r * ld + c + 1, img[r * SP + c + 1]);
+        }
+    }
+}
+// every storing wave has drained; one lane raises the flag
+__device__ __forceinline__ void ct_signal(int* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) ct_sti(flag, 1);
+}
+// tile of the source matrix -> accumulator layout (rows 16*(2i+wm)+lq+4r, columns 32*wn+16j+lr), zero padded
+__device__ __forceinline__ void ct_load_acc(acc64_t& acc, const double* __restrict__ G, int64_t ld, int mr, int mc) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * (2 * i + wm) + lq + 4 * r, col = 32 * wn + 16 * j + lr;
+                acc[i][j][r] = (row < mr && col < mc) ? G[(int64_t)row * ld + col] : 0.0;
+            }
+}
+// accumulators -> LDS image (stride SP).  DIAG: lower part, zeros above, identity beyond bs (what potrf64_blk reads)
+template <bool DIAG>
+__device__ __forceinline__ void ct_acc_to_img(double* __restrict__ img, const acc64_t& acc, int bs) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * (2 * i + wm) + lq + 4 * r, col = 32 * wn + 16 * j + lr;
+                double v = acc[i][j][r];
+                if (DIAG) v = (row < bs && col < bs && col <= row) ? v : ((row == col) ? 1.0 : 0.0);
+                img[row * SP + col] = v;
+            }
+}
+// P = As * Bs^T for two 64x64 images with row strides SA, SB, then acc -= P (the product is formed from zero and
+// subtracted, as chol_step_kernel does through sub_acc64)
+template <int SA, int SB>
+__device__ __forceinline__ void ct_update(acc64_t& acc, const double* __restrict__ As, const double* __restrict__ Bs) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lq = lane >> 4;
+    const double* ap = As + (16 * wm + lr) * SA + lq;
+    const double* bp = Bs + (32 * wn + lr) * SB + lq;
+    d4 p00 = d4{0.0, 0.0, 0.0, 0.0}, p01 = p00, p10 = p00, p11 = p00;
+#pragma unroll 4
+    for (int kk = 0; kk < NB / 4; ++kk) {
+        const double a0 = ap[4 * kk], a1 = ap[32 * SA + 4 * kk];
+        const double b0 = bp[4 * kk], b1 = bp[16 * SB + 4 * kk];
+        p00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, p00, 0, 0, 0);
+        p01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, p01, 0, 0, 0);
+        p10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, p10, 0, 0, 0);
+        p11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, p11, 0, 0, 0);
+    }
+    acc[0][0] -= p00; acc[0][1] -= p01; acc[1][0] -= p10; acc[1][1] -= p11;
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void chol_tiles_kernel(CholInst one, const CholInst* __restrict__ table,
+                                                                const CholJob* __restrict__ jobs, int64_t ld, int64_t m,
+                                                                int T, long long spin_limit, int stall_test) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* R0 = lds;                           // operand image (stride SQ) / tile image (stride SP)
+    double* R1 = R0 + NB * SQ;                  // operand image / factor image
+    double* tbuf = R1 + NB * SQ;                // 4 * POTRF_TB: 16x16 factor copies + reciprocals of a block column
+    int* word = reinterpret_cast<int*>(tbuf + 4 * POTRF_TB);      // outcome of the last wait
+    int* badflag = word + 2;
+    double* red = tbuf + 4 * POTRF_TB + 8;
+
+    const CholInst ci = (table != nullptr) ? table[blockIdx.y] : one;
+    const CholJob job = jobs[blockIdx.x];
+    const int tid = threadIdx.x;
+    const bool diagrole = (job.i == job.j);
+    const int d = job.i;
+    const bool has_off = !diagrole || d > 0;
+    const int ti = job.i, tj = diagrole ? d - 1 : job.j;          // the off-diagonal tile of this workgroup
+    int* abortw = ci.flags + FLAG_ABORT;
+    auto blk = [&](int b) { return (int)min((int64_t)NB, m - (int64_t)b * NB); };
+    auto at = [&](auto* base, int bi, int bj) { return base + (int64_t)bi * NB * ld + (int64_t)bj * NB; };
+    if (stall_test && blockIdx.x == 0) return;                    // test hook: block column 0 is never published
+
+    acc64_t accO, accD;
+    const int mi = blk(ti);
+    if (has_off) ct_load_acc(accO, at(ci.src, ti, tj), ld, mi, blk(tj));
+    if (diagrole) ct_load_acc(accD, at(ci.src, d, d), ld, blk(d), blk(d));
+
+    double run_logdet = 0.0, run_bad = 0.0;
+    if (has_off) {
+        // ---- rank-64 updates from the block columns left of the tile
+        for (int k = 0; k < tj; ++k) {
+            if (!ct_wait(ci.ready + ti * T + k, ci.ready + tj * T + k, abortw, spin_limit, word)) return;
+            ct_fetch<SQ, false>(R0, at(ci.L, ti, k), ld, mi, NB);
+            ct_fetch<SQ, false>(R1, at(ci.L, tj, k), ld, blk(tj), NB);
+            __syncthreads();
+            ct_update<SQ, SQ>(accO, R0, R1);
+            if (diagrole) ct_update<SQ, SQ>(accD, R0, R0);
+        }
+        // ---- panel solve against the factor of block column tj:  X L(tj,tj)^T = tile
+        if (!ct_wait(ci.ready + tj * T + tj, nullptr, abortw, spin_limit, word)) return;
+        ct_fetch<SP, true>(R1, at(ci.Ldiag, tj, tj), ld, NB, NB);
+        {
+            const double* ax = ci.aux + (int64_t)tj * CT_AUX;
+            for (int e = tid; e < 4 * POTRF_TB; e += NTHREADS) tbuf[e] = ct_ld(ax + e);
+            run_logdet = ct_ld(ax + 4 * POTRF_TB);
+            run_bad = ct_ld(ax + 4 * POTRF_TB + 1);
+        }
+        ct_acc_to_img<false>(R0, accO, NB);
+        __syncthreads();
+        trsm64_blk(R0, R1, tbuf);
+        __syncthreads();
+        ct_publish<false>(R0, at(ci.L, ti, tj), ld, mi, blk(tj));
+        ct_signal(ci.ready + ti * T + tj);
+        if (!diagrole) return;
+        ct_update<SP, SP>(accD, R0, R0);                          // the last update of the diagonal tile: our own panel block
+        __syncthreads();
+    }
+    // ---- diagonal tile: factor, publish, log-determinant, inverse
+    const int bs = blk(d);
+    ct_acc_to_img<true>(R1, accD, bs);
+    if (tid == 0) *badflag = 0;
+    __syncthreads();
+    potrf64_blk(R1, R0, tbuf, badflag, bs);                       // factor in R0; ends with a barrier
+    double lg = (tid < bs) ? log(R0[tid * SP + tid]) : 0.0;
+    for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off);
+    if ((tid & 63) == 0) red[tid >> 6] = lg;
+    __syncthreads();
+    const double logdet = run_logdet + 2.0 * (red[0] + red[1] + red[2] + red[3]);     // block columns in order
+    const double bad = (*badflag != 0 || run_bad != 0.0) ? 1.0 : 0.0;
+    ct_publish<true>(R0, at(ci.Ldiag, d, d), ld, bs, bs);
+    {
+        double* ax = ci.aux + (int64_t)d * CT_AUX;
+        for (int e = tid; e < 4 * POTRF_TB; e += NTHREADS) ct_st(ax + e, tbuf[e]);
+        if (tid == 0) { ct_st(ax + 4 * POTRF_TB, logdet); ct_st(ax + 4 * POTRF_TB + 1, bad); }
+    }
+    ct_signal(ci.ready + d * T + d);
+    if (d == T - 1 && tid == 0) {
+        *ci.logdet = logdet;
+        if (bad != 0.0) ci.flags[FLAG_NOT_PD] = 1;
+    }
+    if (ci.Winv != nullptr) {
+        // inverse of the diagonal block for W = L^-1 (off every chain): X L^T = I gives X = W^T
+        for (int e = tid; e < NB * NB; e += NTHREADS) R1[(e >> 6) * SP + (e & 63)] = ((e >> 6) == (e & 63)) ? 1.0 : 0.0;
+        __syncthreads();
+        trsm64_blk(R1, R0, tbuf);
+        __syncthreads();
+        double* Wkk = at(ci.Winv, d, d);
+        for (int e = tid; e < NB * NB; e += NTHREADS) {
+            const int r = e >> 6, c = e & 63;
+            if (r < bs && c < bs) Wkk[(int64_t)r * ld + c] = (c <= r) ? R1[c * SP + r] : 0.0;
+        }
+    }
+}
+
 // Inverse of every 64x64 diagonal block of L: thread j solves L11 w = e_j (column j of the
 // inverse).  The block is written whole, zeros above the diagonal included.
 __global__ __launch_bounds__(64) void trtri_diag_kernel(const double* __restrict__ L, int64_t ldl,
@@ -1329,9 +1609,10 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(const double* __restrict
 
 // resets the scalars and the status flags; with x != NULL also the x >= 0 check of functions.py:45
 __global__ __launch_bounds__(1024) void zero_scalars_kernel(double* dscal, int* dflag, const double* __restrict__ x,
-                                                          int64_t n) {
+                                                          int64_t n, int* __restrict__ ready, int nready) {
     if (threadIdx.x < 8) __hip_atomic_store(dscal + threadIdx.x, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x < 4) dflag[threadIdx.x] = 0;
+    if (threadIdx.x < 8) dflag[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < nready; i += blockDim.x) ready[i] = 0;     // hand-off flags of the one-launch Cholesky
     if (x == nullptr) return;
     bool bad = false;
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
@@ -1643,6 +1924,28 @@ int build_plans(accbpg_dopt* h) {
     }
     ACC_HIP(hipMalloc(&h->chol_op, sizeof(GemmOp) * (size_t)(T + 1)));
 
+    // ---- one-launch Cholesky: a workgroup per tile (the owner of a diagonal tile also owns the tile left of it)
+    if (T <= CT_TMAX) {
+        std::vector<CholJob> jobs;
+        for (int d2 = 0; d2 < T; ++d2) jobs.push_back(CholJob{d2, d2});            // the chain first
+        for (int j = 0; j < T; ++j)                                               // then by urgency: leftmost columns
+            for (int i = j + 2; i < T; ++i) jobs.push_back(CholJob{i, j});
+        ACC_TRY(set_lds(chol_tiles_kernel, CT_LDS_BYTES));
+        int per_cu = 0;
+        ACC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chol_tiles_kernel, NTHREADS, CT_LDS_BYTES));
+        h->chol_tiles_grid = (int)jobs.size();
+        h->chol_tiles_ok = per_cu >= 1 && (int64_t)jobs.size() <= (int64_t)std::min(per_cu, 2) * h->num_cu;
+        if (h->chol_tiles_ok) {
+            ACC_HIP(hipMalloc(&h->chol_jobs, sizeof(CholJob) * jobs.size()));
+            ACC_HIP(hipMemcpy(h->chol_jobs, jobs.data(), sizeof(CholJob) * jobs.size(), hipMemcpyHostToDevice));
+            ACC_HIP(hipMalloc(&h->chol_ready, sizeof(int) * (size_t)T * T));
+            ACC_HIP(hipMemset(h->chol_ready, 0, sizeof(int) * (size_t)T * T));
+            ACC_HIP(hipMalloc(&h->chol_aux, sizeof(double) * (size_t)T * CT_AUX));
+            ACC_HIP(hipMalloc(&h->Gbuf, sizeof(double) * (size_t)m * m));
+            ACC_HIP(hipMemset(h->Gbuf, 0, sizeof(double) * (size_t)m * m));
+        }
+    }
+
     ACC_TRY(set_lds(gram_streamk_kernel<TileBig<false, true>>, TileBig<false>::LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<TileBig<false, false>>, TileBig<false>::LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<TileSmall<false, true>>, TileSmall<false>::LDS_BYTES));
@@ -1790,11 +2093,56 @@ int launch_gemm_ops(const GemmOp* ops_dev, int nops, int maxM, int maxN, bool b_
 
 // In-place Cholesky of the lower triangle of A (m x m, ld m).  Resets and fills dscal[0] (log det)
 // and dflag[FLAG_NOT_PD].  T = ceil(m/64) launches.
-int launch_cholesky(accbpg_dopt* h, double* A, double* Winv, const double* xcheck) {
+// The one-launch kernel needs all of its workgroups resident together, so two of them must never share the chip:
+// launches of this process are chained through one event per device (the second waits for the first to finish;
+// everything else on the streams still overlaps).  Another PROCESS on the same GPU is what the bounded spins are for.
+static std::mutex g_tiles_mu;
+static hipEvent_t g_tiles_ev[64] = {};
+static hipStream_t g_tiles_stream[64] = {};
+static bool g_tiles_any[64] = {};
+
+bool chol_tiles_usable(const accbpg_dopt* h) {
+    return h->chol_tiles_ok && !h->chol_tiles_off && (h->chol_dbg & 63) == 0;
+}
+
+static int launch_chol_tiles(accbpg_dopt* h, const double* src, double* A, double* Winv) {
     const int64_t m = h->m;
     const int T = (int)((m + NB - 1) / NB);
+    CholInst ci;
+    ci.src = src; ci.L = A; ci.Ldiag = h->Tbuf; ci.Winv = Winv; ci.logdet = h->dscal; ci.flags = h->dflag;
+    ci.ready = h->chol_ready; ci.aux = h->chol_aux;
+    const int dev = h->device;
+    std::lock_guard<std::mutex> lk(g_tiles_mu);
+    if (dev >= 0 && dev < 64) {
+        if (!g_tiles_ev[dev]) ACC_HIP(hipEventCreateWithFlags(&g_tiles_ev[dev], hipEventDisableTiming));
+        if (g_tiles_any[dev] && g_tiles_stream[dev] != h->stream) ACC_HIP(hipStreamWaitEvent(h->stream, g_tiles_ev[dev], 0));
+    }
+    chol_tiles_kernel<<<dim3(h->chol_tiles_grid, 1), NTHREADS, CT_LDS_BYTES, h->stream>>>(
+        ci, nullptr, reinterpret_cast<const CholJob*>(h->chol_jobs), m, m, T, h->chol_spin_limit, h->chol_stall_test);
+    ACC_HIP(hipGetLastError());
+    if (dev >= 0 && dev < 64) {
+        ACC_HIP(hipEventRecord(g_tiles_ev[dev], h->stream));
+        g_tiles_stream[dev] = h->stream;
+        g_tiles_any[dev] = true;
+    }
+    return ACCBPG_OK;
+}
+
+int launch_cholesky(accbpg_dopt* h, double* A, double* Winv, const double* xcheck, const double* src) {
+    const int64_t m = h->m;
+    const int T = (int)((m + NB - 1) / NB);
+    if (src == nullptr) src = A;
+    const bool tiles = chol_tiles_usable(h);
     prof_begin(h, PROF_CHOL);
-    zero_scalars_kernel<<<1, xcheck ? 1024 : 64, 0, h->stream>>>(h->dscal, h->dflag, xcheck, h->n);
+    zero_scalars_kernel<<<1, (xcheck || tiles) ? 1024 : 64, 0, h->stream>>>(h->dscal, h->dflag, xcheck, h->n,
+                                                                          tiles ? h->chol_ready : nullptr, tiles ? T * T : 0);
+    if (tiles) {
+        ACC_TRY(launch_chol_tiles(h, src, A, Winv));
+        h->diag_inv_ready = (Winv != nullptr);
+        prof_end(h, PROF_CHOL);
+        return ACCBPG_OK;
+    }
+    if (src != A) ACC_TRY(device_copy(A, src, (size_t)m * m, h->stream));
     // One level (every launch updates the whole trailing matrix) up to chol_two_level_T block columns; beyond,
     // outer panels of chol_nk (8) block columns: the step launches stay inside the panel, chol_syrk_kernel
     // applies the panel to the rest in one pass.

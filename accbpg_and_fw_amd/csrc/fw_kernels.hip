@@ -310,7 +310,7 @@ static int fw_nsplit(const accbpg_dopt* h) { return vt_nsplit(h->m, h->n, h->num
 
 static int read_scalars(accbpg_dopt* h, int nd, int ni) {
     (void)nd; (void)ni;
-    ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * 18, hipMemcpyDeviceToHost, h->stream));   // scalars + flags
+    ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * STATUS_DOUBLES, hipMemcpyDeviceToHost, h->stream));   // scalars + flags
     ACC_HIP(hipStreamSynchronize(h->stream));
     return ACCBPG_OK;
 }
@@ -320,10 +320,15 @@ extern "C" int accbpg_fw_init(accbpg_dopt* h, const double* x0_dev, double* logd
     ACC_TRY(fw_alloc(h));
     const int64_t m = h->m;
     ACC_TRY(device_copy(h->fw_x, x0_dev, (size_t)h->n, h->stream));
-    ACC_TRY(launch_gram(h, h->fw_x, h->Lbuf));                 // D_opt_alg.py:40
-    ACC_TRY(launch_cholesky(h, h->Lbuf));                      // det / inv via the Cholesky factor (:41-42)
+    double* gram = chol_tiles_usable(h) ? h->Gbuf : h->Lbuf;
+    ACC_TRY(launch_gram(h, h->fw_x, gram));                    // D_opt_alg.py:40
+    ACC_TRY(launch_cholesky(h, h->Lbuf, nullptr, nullptr, gram));   // det / inv via the Cholesky factor (:41-42)
     ACC_TRY(read_scalars(h, 1, 4));
     const int* fl = reinterpret_cast<const int*>(h->hpin + 16);
+    if (fl[FLAG_ABORT] && !h->chol_tiles_off) {                // one-launch factorisation abandoned: launch per block column
+        h->chol_tiles_off = true;
+        return accbpg_fw_init(h, x0_dev, logdet_gram_host);
+    }
     if (fl[FLAG_NOT_PD]) {
         set_last_error("accbpg_fw_init: V diag(x0) V^T is singular or not positive definite");
         return ACCBPG_ERR_NOT_PD;
@@ -349,15 +354,19 @@ extern "C" int accbpg_fw_init(accbpg_dopt* h, const double* x0_dev, double* logd
 
 extern "C" int accbpg_fw_probe_step(accbpg_dopt* h, int away, int refresh_logdet, accbpg_fw_probe* out) {
     if (!h || !out || !h->fw_ready) return ACCBPG_ERR_ARG;
-    const int64_t m = h->m;
     double logdet = 0.0;
     if (refresh_logdet) {
         // F[k] = log det(H) from a fresh factorisation of the maintained inverse (D_opt_alg.py:136)
-        ACC_TRY(device_copy(h->Lbuf, h->fw_H, (size_t)m * m, h->stream));
-        ACC_TRY(launch_cholesky(h, h->Lbuf));
+        // (the factor goes to Lbuf; H itself is read in place by the one-launch kernel, copied otherwise)
+        ACC_TRY(launch_cholesky(h, h->Lbuf, nullptr, nullptr, h->fw_H));
         ACC_TRY(read_scalars(h, 1, 4));
-        logdet = h->hpin[0];
         const int* fl = reinterpret_cast<const int*>(h->hpin + 16);
+        if (fl[FLAG_ABORT] && !h->chol_tiles_off) {
+            h->chol_tiles_off = true;
+            ACC_TRY(launch_cholesky(h, h->Lbuf, nullptr, nullptr, h->fw_H));
+            ACC_TRY(read_scalars(h, 1, 4));
+        }
+        logdet = h->hpin[0];
         if (fl[FLAG_NOT_PD]) logdet = __builtin_nan("");
     }
     int64_t* iout = reinterpret_cast<int64_t*>(h->dscal + 8);

@@ -60,6 +60,9 @@ constexpr int FLAG_NOT_PD = 0;  // index into the device flag array
 constexpr int FLAG_NEG_X = 1;
 constexpr int FLAG_NONPOS = 2;
 constexpr int FLAG_BAD_G = 3;
+constexpr int FLAG_ABORT = 4;   // the one-launch Cholesky gave up a wait (co-residency not reached in time)
+constexpr int STATUS_DOUBLES = 20;   // 16 scalars + 8 status flags, copied to the host in one piece
+constexpr int ACCBPG_RETRY = 100;    // internal: redo the evaluation with the launch-per-column Cholesky
 
 enum ProfKind { PROF_GRAM = 0, PROF_CHOL = 1, PROF_TRTRI = 2, PROF_GRAD = 3, PROF_GRAMFIX = 4, PROF_COUNT = 5 };
 
@@ -118,6 +121,19 @@ struct accbpg_dopt {
     int chol_nk = 8;            // block columns per outer panel of the two-level scheme
     int chol_two_level_T = 64;  // block columns from which the Cholesky runs its two-level scheme (m > 4032)
     int chol_dbg = 0;           // timing ablation bits for chol_step_kernel (0 in production)
+    // one-launch Cholesky (tile owners, T <= 32 block columns)
+    bool chol_tiles_ok = false;     // the grid fits the chip (checked against the occupancy query at creation)
+    bool chol_tiles_off = false;    // switched off (debug bit, or after a wait timed out)
+    int chol_stall_test = 0;        // debug: make the launch time out
+    long long chol_spin_limit = 20000000;   // 0.2 s of the 100 MHz wall clock
+    int chol_tiles_grid = 0;
+    void* chol_jobs = nullptr;      // CholJob[chol_tiles_grid]
+    int* chol_ready = nullptr;      // T*T hand-off flags
+    double* chol_aux = nullptr;     // T * CT_AUX doubles
+    double* Gbuf = nullptr;         // m*m: Gram matrix of func_grad when the one-launch Cholesky is in use (kept intact for a redo)
+    const double* last_x = nullptr; // arguments of the evaluation in flight (for a redo)
+    double* last_g = nullptr;
+    int last_flag = 0;
     hipEvent_t ev_done = nullptr;   // recorded behind the result copy of every begin/end evaluation
     bool prof_on = false;
     accbpg::ProfSlot prof[accbpg::PROF_COUNT];
@@ -127,8 +143,10 @@ namespace accbpg {
 
 // dopt_kernels.hip
 int launch_gram(accbpg_dopt* h, const double* x, double* gram);
-int launch_cholesky(accbpg_dopt* h, double* A /* m*m, in place */, double* Winv = nullptr /* diagonal-block inverses */,
-                    const double* xcheck = nullptr /* x >= 0 check folded into the reset launch */);
+int launch_cholesky(accbpg_dopt* h, double* A /* m*m, factor goes here */, double* Winv = nullptr /* diagonal-block inverses */,
+                    const double* xcheck = nullptr /* x >= 0 check folded into the reset launch */,
+                    const double* src = nullptr /* matrix to factor when it is not A itself */);
+bool chol_tiles_usable(const accbpg_dopt* h);
 int launch_trtri(accbpg_dopt* h);
 int launch_colnorm(accbpg_dopt* h, const double* W, double* out, double sign);
 int launch_gemm_ops(const GemmOp* ops_dev, int nops, int maxM, int maxN, bool b_kmajor, hipStream_t s);

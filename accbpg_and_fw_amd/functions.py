@@ -349,7 +349,9 @@ class DOptimalObj(RSmoothFunction):
         return [h for h in (self._h, getattr(self, "_h2", None)) if h]
 
     def profile(self, enable=True):
-        """HIP-event timing of every kernel family on the stream it is launched on (both evaluation handles)."""
+        """HIP-event timing of every kernel family on the stream it is launched on.  While it is on, the
+        solvers keep F[k] = f(x) on their own stream (no side-stream overlap), so that the durations are those
+        of kernels that have the chip to themselves."""
         self._prof = bool(enable)
         for h in self._handles():
             self._lib.accbpg_dopt_profile_enable(h, 1 if enable else 0)

@@ -373,7 +373,7 @@ def test_housing_rng_free(acc):
 
 
 # ------------------------------------------------------------------ Frank-Wolfe
-@pytest.mark.parametrize("tag", ["30x1000", "64x512"])
+@pytest.mark.parametrize("tag", ["30x1000", "64x512", "256x4096"])
 def test_fw_trajectories(acc, tag):
     gd = golden("fw_" + tag)
     m, n, seed, iters = int(gd["m"]), int(gd["n"]), int(gd["seed"]), int(gd["iters"])
@@ -456,6 +456,75 @@ def test_large_abpg_gain_trajectory_2048x32768(large, acc):
     _close(F, gd["F"], 1e-9); _close(Gain, gd["Gain"], 1e-12); _close(Gdiv, gd["Gdiv"], 1e-7)
 
 
+def test_large_abpg_gain_past_first_retries_2048x32768(large, acc):
+    """The headline solver at the headline size through the first line-search retries: 64 iterations of
+    ABPG_gain(gamma=2) at D_opt_design(2048,32768) against the trace of the real reference
+    (oracle/gen_golden.py --only-large-gain-long; accbpg/algorithms.py:361-390).  The fixture holds the
+    gain sequence, the value EVERY oracle call returned in call order (rejected trial points included), and
+    iterates x_k along the run.  Required: the same accept/reject decisions (identical gain sequence and call
+    pattern), every evaluated objective value to 1e-9, l_inf(x_k) < 1e-9 at every stored iterate."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "large_gain_long.npz")):
+        pytest.skip("tests/golden/large_gain_long.npz not generated")
+    f, h, L, x0, _ = large
+    gd = golden("large_gain_long")
+    iters = int(gd["iters"])
+    ref_gain = gd["Gain"]
+    retries = np.flatnonzero(ref_gain[1:] > ref_gain[:-1] / 1.2 * (1 + 1e-12)) + 1
+    assert retries.size >= 10, "fixture must contain line-search retries"     # the regime the solver lives in
+
+    kinds, values, iterates = [], [], {}
+    keep = set(int(k) for k in gd["keep"])
+    inner_value, inner_fg = f.__call__, f.func_grad
+
+    class Logged:
+        """Pass-through that notes kind and returned value of every oracle call, like the generator's."""
+        m, n, H = f.m, f.n, f.H
+        device = f.device
+        _overlap = False                                        # calls then arrive in the reference's order
+        _lin = False
+
+        def __call__(self, x):
+            v = inner_fg(x, 0)
+            kinds.append(0); values.append(v)
+            return v
+
+        def func_grad(self, x, flag=2):
+            out = inner_fg(x, flag)
+            kinds.append(flag); values.append(out[0] if flag == 2 else float("nan"))
+            return out
+
+        def gradient(self, x):
+            return self.func_grad(x, 1)
+
+    from accbpg_and_fw_amd.algorithms import ABPG_gain_steps
+    xd = torch.from_numpy(x0).cuda()
+    gen = ABPG_gain_steps(Logged(), h, L, xd, 2, iters, verbose=False)
+    result = None
+    while True:
+        try:
+            next(gen)
+        except StopIteration as stop:
+            result = stop.value
+            break
+    x, F, Gain, Gdiv, Gavg, T = result
+    assert len(F) == iters
+    np.testing.assert_array_equal(np.array(kinds, dtype=np.int8), gd["call_kinds"])     # same call pattern
+    _close(Gain, ref_gain, 1e-12)                                                       # same decisions
+    _close(np.array(values), gd["call_values"], 1e-9)                                   # every evaluated value
+    _close(F, gd["F"], 1e-9); _close(Gavg, gd["Gavg"], 1e-11); _close(Gdiv, gd["Gdiv"], 1e-6)
+    assert np.max(np.abs(x.cpu().numpy() - gd["x"])) < 1e-9
+    # iterates along the run: rerun to each stored k (the solver is deterministic) -- the shortest prefixes only
+    for k in sorted(keep)[:3]:
+        xk = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=k, verbose=False)[0]
+        assert np.max(np.abs(xk - gd["x_%d" % k])) < 1e-9, k
+    # the mix in the retry regime: about 2 gradient and 3 value evaluations per iteration
+    pos = gd["iter_call_pos"]
+    tail = slice(int(pos[40]), int(pos[60]))
+    kk = np.array(kinds)[tail]
+    assert 1.7 <= np.sum(kk == 2) / 20 <= 2.3 and 2.6 <= np.sum(kk == 0) / 20 <= 3.4
+
+
 def test_large_long_trajectories_2048x32768(large, acc):
     """Config 2, longer horizon: 120 iterations of ABPG(gamma=2, theta_eq=True) and 60 of BPG with line
     search against traces of the real reference (oracle/gen_golden.py --only-large-long, about 1.5 h of
@@ -489,6 +558,67 @@ def test_large_fw_2048x32768(large, acc):
     _close(F, gd["away_F"], 1e-8); _close(SP, gd["away_SP"], 1e-9)
 
 
+# ------------------------------------------------------------------ one-launch Cholesky (tile owners)
+@pytest.mark.parametrize("m", [64, 100, 128, 512, 520, 1000, 1024, 1984, 2048])
+def test_tile_cholesky_matches_step_kernels(acc, O, m):
+    """The one-launch Cholesky (a workgroup per 64x64 tile, hand-offs inside the launch) against the launch-per-
+    block-column kernels on the same matrices: the same arithmetic in the same order, so value and gradient --
+    which see the factor, the log-determinant and the inverse of the factor -- are BIT-identical; and both
+    against the oracle.  Ragged last blocks, one block, the largest size the scheme covers."""
+    from accbpg_and_fw_amd import _lib
+    n = m + 200 + (m % 7)
+    V = gaussian_design(m, n, 40 + m % 13)
+    rng = np.random.RandomState(m)
+    f_tiles = acc.DOptimalObj(V)
+    f_steps = acc.DOptimalObj(V)
+    _lib.load().accbpg_debug_chol_variant(f_steps._h, 64)        # bit 6: launch per block column
+    fo = O.DOptOracle(V)
+    for trial in range(3):
+        x = rng.rand(n) + 0.01
+        x /= x.sum()
+        a, ga = f_tiles.func_grad(x, 2)
+        b, gb = f_steps.func_grad(x, 2)
+        assert a == b
+        np.testing.assert_array_equal(ga, gb)
+        assert f_tiles(x) == a
+        fr, gr = fo.func_grad(x, 2)
+        assert abs(a - fr) < 1e-11 * max(1.0, abs(fr))
+        np.testing.assert_allclose(ga, gr, rtol=1e-10)
+    # not positive definite / negative entries: same error behaviour through the new path
+    xz = np.zeros(n); xz[: m // 2] = 1.0 / (m // 2)
+    with pytest.raises(ValueError):
+        f_tiles(xz)
+    xn = x.copy(); xn[3] = -1e-3
+    with pytest.raises(AssertionError):
+        f_tiles(xn)
+    assert f_tiles(x) == a                                       # and the handle is fine afterwards
+
+
+def test_tile_cholesky_gives_up_and_redoes(acc):
+    """A wait inside the one-launch Cholesky that is never satisfied (here: a test hook keeps block column 0
+    unpublished) ends the launch by its bounded spin instead of hanging it; the evaluation is redone with the
+    launch-per-block-column kernels and the handle stays on them."""
+    import time
+    from accbpg_and_fw_amd import _lib
+    f, h, L, x0 = acc.D_opt_design(512, 2048, randseed=3)
+    want = f.func_grad(x0, 2)
+    g = acc.DOptimalObj(f.H)
+    _lib.load().accbpg_debug_chol_variant(g._h, 128)             # bit 7: stall + 2 ms spin limit
+    t0 = time.time()
+    got = g.func_grad(x0, 2)
+    assert time.time() - t0 < 5.0
+    assert got[0] == want[0]
+    np.testing.assert_array_equal(got[1], want[1])
+    assert g(x0) == want[0]
+    # the Frank-Wolfe refactorisation path (reads H in place) redoes the same way
+    g2 = acc.DOptimalObj(f.H)
+    _lib.load().accbpg_debug_chol_variant(g2._h, 128)
+    xa, Fa, SPa, SNa, Ta = acc.D_opt_FW_away(g2, x0, 1e-8, 5, verbose=False)
+    xb, Fb, SPb, SNb, Tb = acc.D_opt_FW_away(f, x0, 1e-8, 5, verbose=False)
+    np.testing.assert_array_equal(xa, xb)
+    np.testing.assert_array_equal(Fa, Fb)
+
+
 # ------------------------------------------------------------------ sharding (one device, logical shards)
 @pytest.mark.parametrize("shape,parts", [((96, 1000), 3), ((1024, 4096), 8), ((300, 1111), 4), ((2048, 8192), 4),
                                          ((4096, 16384), 2)])
@@ -508,6 +638,13 @@ def test_logical_shards_match_single_device(acc, shape, parts):
     assert abs(f1 - f2) < 1e-11 * max(1.0, abs(f1))
     np.testing.assert_allclose(g2, g1, rtol=1e-11)
     assert fs(x) == f2
+    # accbpg/functions.py:45 on the sharded path: one negative (or NaN) entry in ONE shard raises the
+    # reference's assertion, also when the summed Gram matrix is still positive definite
+    for bad_value in (-1e-9, np.nan):
+        xb = x.copy()
+        xb[n - 2] = bad_value
+        with pytest.raises(AssertionError):
+            fs(xb)
     h = acc.BurgEntropySimplex()
     x0 = np.ones(n) / n
     xa, Fa, Ga, Ta = acc.ABPG(f, h, 1.0, x0, gamma=2, maxitrs=15, verbose=False)
@@ -699,25 +836,60 @@ def test_runs_are_bitwise_reproducible(acc, shape):
             np.testing.assert_array_equal(p, q)
 
 
-def test_overlapped_value_evaluation_is_identical(acc):
-    """Opt-in: F[k] = f(x) on a side stream beside func_grad(y).  Same kernels on the same data, so
-    the whole run is bitwise identical to the sequential one."""
-    f, h, L, x0 = acc.D_opt_design(300, 3000, randseed=21)
+@pytest.mark.parametrize("shape", [(300, 3000), (512, 8192), (1024, 4096)])
+def test_overlapped_value_evaluation_is_identical(acc, shape):
+    """The default: F[k] = f(x) on a side stream beside func_grad(y).  Same kernels on the same data, so
+    the whole run is bitwise identical to the one with both evaluations on the solver's stream."""
+    f, h, L, x0 = acc.D_opt_design(shape[0], shape[1], randseed=21)
+    assert f._overlap                                           # on unless switched off
+    f.overlap_values(False)
     a = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=60, verbose=False)
     b = acc.ABPG(f, h, L, x0, gamma=2.0, maxitrs=60, theta_eq=True, restart=True, verbose=False)
     f.overlap_values(True)
     a2 = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=60, verbose=False)
     b2 = acc.ABPG(f, h, L, x0, gamma=2.0, maxitrs=60, theta_eq=True, restart=True, verbose=False)
-    f.overlap_values(False)
     for u, v in [(a, a2), (b, b2)]:
         for p, q in zip(u[:-1], v[:-1]):
             np.testing.assert_array_equal(p, q)
     # an error inside the overlapped evaluation surfaces at the wait
-    f.overlap_values(True)
     bad = torch.from_numpy(-x0).cuda()
     with pytest.raises(AssertionError):
         f.value_wait(f.value_async(bad))
-    f.overlap_values(False)
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("solver", ["abpg", "abpg_gain"])
+def test_time_stamps_mark_when_F_was_known(acc, overlap, solver):
+    """T[k] is stamped when F[k] = f(x) is known, as the reference does right after computing it
+    (accbpg/algorithms.py:135-137, 347-349) -- not after the gradient evaluation that follows.  The gradient is
+    delayed by 60 ms on the host: T[0] must not contain that delay, later gaps must."""
+    import time
+    f, h, L, x0 = acc.D_opt_design(256, 4096, randseed=5)
+    f.overlap_values(overlap)
+    f.func_grad(x0, 2)                                          # first-use costs out of the way
+    if overlap:
+        f.value_wait(f.value_async(torch.from_numpy(x0).cuda()))
+    slow = f.func_grad
+
+    def delayed(x, flag=2):
+        if flag != 0:
+            time.sleep(0.06)
+        return slow(x, flag)
+
+    f.func_grad = delayed
+    f.gradient = lambda x: delayed(x, 1)
+    try:
+        t0 = time.time()
+        if solver == "abpg":
+            out = acc.ABPG(f, h, L, x0, gamma=2.0, maxitrs=4, verbose=False)
+        else:
+            out = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=4, verbose=False)
+        wall = time.time() - t0
+    finally:
+        del f.func_grad, f.gradient
+    T = out[-1]
+    assert 0 <= T[0] < 0.045, T                                 # the first value was known before the slow gradient
+    assert np.all(np.diff(T) >= 0.055) and T[-1] <= wall        # every later stamp has one delay more behind it
 
 
 # ------------------------------------------------------------------ SURVEY 8(f) row 4: Poisson + Burg L1/L2
@@ -778,6 +950,24 @@ def test_poisson_shapes_against_oracle(acc, O, shape):
     fx, g = f.func_grad(x, 2)
     assert fx == pytest.approx(fo, rel=1e-13)
     np.testing.assert_allclose(g, go, rtol=1e-12, atol=1e-13 * np.abs(go).max())
+
+
+def test_poisson_long_rows_branch_against_oracle(acc, O):
+    """(2048, 32768), 512 MiB of A: the wave-per-row A x kernel with its occupancy-limiting LDS request
+    (m >= 8 CUs' worth of rows, n >= 32768) and the A^T r pass at that shape's row split, against the oracle:
+    A x, f and g."""
+    m, n = 2048, 32768
+    rng = np.random.RandomState(12)
+    A = rng.rand(m, n)
+    b = rng.rand(m) + 0.1
+    x = rng.rand(n) / n + 1e-5
+    fo, go = O.PoissonOracle(A, b).func_grad(x, 2)
+    f = acc.PoissonRegression(A, b)
+    fx, g = f.func_grad(x, 2)
+    np.testing.assert_allclose(f.fitted(), A @ x, rtol=1e-12)
+    assert fx == pytest.approx(fo, rel=1e-12)
+    np.testing.assert_allclose(g, go, rtol=1e-12, atol=1e-13 * np.abs(go).max())
+    assert f(x) == fx
 
 
 def test_poisson_leading_dimension_through_c_abi(acc, O):

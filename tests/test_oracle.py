@@ -75,7 +75,7 @@ def test_solver_traces_match_reference(tag):
         assert abs(F[-1] - gd[key + "_F"][-1]) < 1e-9
 
 
-@pytest.mark.parametrize("tag", ["30x1000", "64x512"])
+@pytest.mark.parametrize("tag", ["30x1000", "64x512", "256x4096"])
 def test_fw_traces_match_reference(tag):
     gd = golden("fw_" + tag)
     m, n, seed, iters = int(gd["m"]), int(gd["n"]), int(gd["seed"]), int(gd["iters"])
