@@ -71,6 +71,7 @@ _SIGS = {
     "accbpg_dopt_profile_reset": (C.c_int, [_P]),
     "accbpg_mfma_f64_peak": (C.c_int, [C.c_int, C.POINTER(C.c_double), _P]),
     "accbpg_debug_chol_variant": (C.c_int, [_P, C.c_int]),
+    "accbpg_debug_chol_trace": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int64)]),
     "accbpg_debug_gram_variant": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "accbpg_test_gemm": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64,
                                    C.c_int64, C.c_int, C.c_double, C.c_double, C.c_int, _P]),

@@ -365,6 +365,30 @@ extern "C" int accbpg_debug_chol_variant(accbpg_dopt* h, int bits) {
     return ACCBPG_OK;
 }
 
+/* Development aid: factor gram_dev once with the one-launch Cholesky while its chain workgroups stamp the 100 MHz
+ * wall clock at their stage boundaries; stamps_host receives 8 stamps per 64-wide block column (workgroup start,
+ * left updates in, previous factor seen, staged, panel solve done, diagonal tile up to date, factored, published). */
+extern "C" int accbpg_debug_chol_trace(accbpg_dopt* h, const double* gram_dev, int with_inverse, int64_t* stamps_host) {
+    if (!h || !gram_dev || !stamps_host) return ACCBPG_ERR_ARG;
+    if (!chol_tiles_usable(h)) {
+        set_last_error("accbpg_debug_chol_trace: the one-launch Cholesky is not in use for this handle");
+        return ACCBPG_ERR_ARG;
+    }
+    const int T = (int)((h->m + NB - 1) / NB);
+    const size_t bytes = sizeof(long long) * (size_t)T * 8;
+    if (!h->chol_trace) ACC_HIP(hipMalloc(&h->chol_trace, bytes));
+    ACC_HIP(hipMemsetAsync(h->chol_trace, 0, bytes, h->stream));
+    int rc = launch_cholesky(h, h->Lbuf, with_inverse ? h->Wbuf : nullptr, nullptr, gram_dev);
+    if (rc == ACCBPG_OK) {
+        hipError_t e = hipMemcpyAsync(stamps_host, h->chol_trace, bytes, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = ACCBPG_ERR_HIP;
+    }
+    hipFree(h->chol_trace);
+    h->chol_trace = nullptr;
+    return rc;
+}
+
 extern "C" int accbpg_debug_gram_variant(accbpg_dopt* h, const double* x_dev, int variant, int iters, double* ms_host) {
     if (!h || !x_dev || !ms_host || iters <= 0) return ACCBPG_ERR_ARG;
     return debug_gram_variant(h, x_dev, variant, iters, ms_host);

@@ -1335,7 +1335,9 @@ struct CholInst {                                  // one factorisation (one ent
     int* flags;             // status flags (FLAG_NOT_PD, FLAG_ABORT)
     int* ready;             // T*T hand-off flags, zero at launch
     double* aux;            // T * CT_AUX doubles
+    long long* trace;       // development aid: CT_NSTAMP wall-clock stamps per block column from the chain workgroups (or null)
 };
+constexpr int CT_NSTAMP = 8;
 
 // Every shared word is accessed as a GLOBAL agent-scope access (global_load / global_store ... sc1), never through
 // a flat pointer: the pointers arrive inside a struct, which hides their address space from the compiler.
@@ -1498,6 +1500,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void chol_tiles_kernel(CholInst one, c
     auto blk = [&](int b) { return (int)min((int64_t)NB, m - (int64_t)b * NB); };
     auto at = [&](auto* base, int bi, int bj) { return base + (int64_t)bi * NB * ld + (int64_t)bj * NB; };
     if (stall_test && blockIdx.x == 0) return;                    // test hook: block column 0 is never published
+    auto stamp = [&](int slot) {
+        if (ci.trace != nullptr && diagrole && tid == 0) ci.trace[d * CT_NSTAMP + slot] = wall_clock64();
+    };
+    stamp(0);                                                     // workgroup started
 
     acc64_t accO, accD;
     const int mi = blk(ti);
@@ -2096,10 +2102,19 @@ int launch_gemm_ops(const GemmOp* ops_dev, int nops, int maxM, int maxN, bool b_
 // The one-launch kernel needs all of its workgroups resident together, so two of them must never share the chip:
 // launches of this process are chained through one event per device (the second waits for the first to finish;
 // everything else on the streams still overlaps).  Another PROCESS on the same GPU is what the bounded spins are for.
+// Small factorisations (few workgroups each) may share the chip as long as ALL the launches in flight fit together:
+// a launch waits for every launch of the process that was issued `together` or more launches before it, where
+// `together` = workgroup slots of the chip / the largest grid among the recent launches.  Because each launch waits
+// for that whole window, everything older has finished too, so at most `together` launches are ever in flight.
 static std::mutex g_tiles_mu;
-static hipEvent_t g_tiles_ev[64] = {};
-static hipStream_t g_tiles_stream[64] = {};
-static bool g_tiles_any[64] = {};
+constexpr int TILES_RING = 16;
+struct TilesRing {
+    hipEvent_t ev[TILES_RING] = {};
+    hipStream_t stream[TILES_RING] = {};
+    int grid[TILES_RING] = {};
+    long long issued = 0;
+};
+static TilesRing g_tiles[64];
 
 bool chol_tiles_usable(const accbpg_dopt* h) {
     return h->chol_tiles_ok && !h->chol_tiles_off && (h->chol_dbg & 63) == 0;
@@ -2110,20 +2125,31 @@ static int launch_chol_tiles(accbpg_dopt* h, const double* src, double* A, doubl
     const int T = (int)((m + NB - 1) / NB);
     CholInst ci;
     ci.src = src; ci.L = A; ci.Ldiag = h->Tbuf; ci.Winv = Winv; ci.logdet = h->dscal; ci.flags = h->dflag;
-    ci.ready = h->chol_ready; ci.aux = h->chol_aux;
-    const int dev = h->device;
+    ci.ready = h->chol_ready; ci.aux = h->chol_aux; ci.trace = h->chol_trace;
+    const int dev = (h->device >= 0 && h->device < 64) ? h->device : 0;
     std::lock_guard<std::mutex> lk(g_tiles_mu);
-    if (dev >= 0 && dev < 64) {
-        if (!g_tiles_ev[dev]) ACC_HIP(hipEventCreateWithFlags(&g_tiles_ev[dev], hipEventDisableTiming));
-        if (g_tiles_any[dev] && g_tiles_stream[dev] != h->stream) ACC_HIP(hipStreamWaitEvent(h->stream, g_tiles_ev[dev], 0));
+    TilesRing& ring = g_tiles[dev];
+    {
+        int gmax = h->chol_tiles_grid;
+        for (int i = 0; i < TILES_RING; ++i) gmax = std::max(gmax, ring.grid[i]);
+        int together = (2 * h->num_cu) / std::max(1, gmax);
+        if (together > TILES_RING - 1) together = TILES_RING - 1;   // (so that the waits of successive launches chain)
+        if (together < 1) together = 1;
+        for (long long back = together; back <= TILES_RING && back <= ring.issued; ++back) {
+            const int slot = (int)((ring.issued - back) % TILES_RING);
+            if (ring.ev[slot] && ring.stream[slot] != h->stream) ACC_HIP(hipStreamWaitEvent(h->stream, ring.ev[slot], 0));
+        }
     }
     chol_tiles_kernel<<<dim3(h->chol_tiles_grid, 1), NTHREADS, CT_LDS_BYTES, h->stream>>>(
         ci, nullptr, reinterpret_cast<const CholJob*>(h->chol_jobs), m, m, T, h->chol_spin_limit, h->chol_stall_test);
     ACC_HIP(hipGetLastError());
-    if (dev >= 0 && dev < 64) {
-        ACC_HIP(hipEventRecord(g_tiles_ev[dev], h->stream));
-        g_tiles_stream[dev] = h->stream;
-        g_tiles_any[dev] = true;
+    {
+        const int slot = (int)(ring.issued % TILES_RING);
+        if (!ring.ev[slot]) ACC_HIP(hipEventCreateWithFlags(&ring.ev[slot], hipEventDisableTiming));
+        ACC_HIP(hipEventRecord(ring.ev[slot], h->stream));
+        ring.stream[slot] = h->stream;
+        ring.grid[slot] = h->chol_tiles_grid;
+        ++ring.issued;
     }
     return ACCBPG_OK;
 }
