@@ -81,7 +81,7 @@ extern "C" int accbpg_dopt_destroy(accbpg_dopt* h) {
     hipFree(h->Lbuf); hipFree(h->Wbuf); hipFree(h->Tbuf); hipFree(h->slabs); hipFree(h->tiles); hipFree(h->wg_ranges); hipFree(h->gram_cstart); hipFree(h->gram_contrib);
     hipFree(h->dscal); hipFree(h->vws); hipFree(h->xbuf); hipFree(h->ops); hipFree(h->chol_op); hipFree(h->red); hipFree(h->Pbuf);
     hipFree(h->fw_x); hipFree(h->fw_w); hipFree(h->fw_H); hipFree(h->fw_hv);
-    hipFree(h->chol_jobs); hipFree(h->chol_ready); hipFree(h->chol_aux); hipFree(h->Gbuf);
+    hipFree(h->chol_jobs); hipFree(h->chol_ready); hipFree(h->chol_aux); hipFree(h->chol_hand); hipFree(h->Gbuf);
     if (h->hpin) hipHostFree(h->hpin);
     if (h->ev_done) hipEventDestroy(h->ev_done);
     for (auto& p : h->prof)
@@ -366,7 +366,7 @@ extern "C" int accbpg_debug_chol_variant(accbpg_dopt* h, int bits) {
 }
 
 /* Development aid: factor gram_dev once with the one-launch Cholesky while its chain workgroups stamp the 100 MHz
- * wall clock at their stage boundaries; stamps_host receives 8 stamps per 64-wide block column (workgroup start,
+ * wall clock at their stage boundaries; stamps_host receives 32 stamps per 64-wide block column (workgroup start,
  * left updates in, previous factor seen, staged, panel solve done, diagonal tile up to date, factored, published). */
 extern "C" int accbpg_debug_chol_trace(accbpg_dopt* h, const double* gram_dev, int with_inverse, int64_t* stamps_host) {
     if (!h || !gram_dev || !stamps_host) return ACCBPG_ERR_ARG;
@@ -375,7 +375,7 @@ extern "C" int accbpg_debug_chol_trace(accbpg_dopt* h, const double* gram_dev, i
         return ACCBPG_ERR_ARG;
     }
     const int T = (int)((h->m + NB - 1) / NB);
-    const size_t bytes = sizeof(long long) * (size_t)T * 8;
+    const size_t bytes = sizeof(long long) * (size_t)T * 32;
     if (!h->chol_trace) ACC_HIP(hipMalloc(&h->chol_trace, bytes));
     ACC_HIP(hipMemsetAsync(h->chol_trace, 0, bytes, h->stream));
     int rc = launch_cholesky(h, h->Lbuf, with_inverse ? h->Wbuf : nullptr, nullptr, gram_dev);

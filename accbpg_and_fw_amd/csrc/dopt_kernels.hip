@@ -807,29 +807,39 @@ __device__ __forceinline__ void solve16_quad(const double* P, double* X, int row
     double pr[4], xs[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) pr[t] = prow[4 * t + q];
-    // every factor entry this lane will need, fetched before the dependent chain starts (the stores of
-    // the results come after it: LDS stores in between would pin the loads behind them)
-    double lv[16][4], rvv[16];
+    // The factor entries this lane needs are fetched four columns at a time, one group ahead of the dependent
+    // chain (the stores of the results come after it: LDS stores in between would pin the loads behind them).
+    // Holding all sixteen columns' entries at once costs 110 registers, which the one-launch Cholesky -- two
+    // workgroups per CU -- does not have.
+    double lv[2][4][4], rvv[2][4];
+    auto group = [&](auto gtag) {
+        constexpr int g = decltype(gtag)::value;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        rvv[c] = rv[c];
+        for (int cc = 0; cc < 4; ++cc) {
+            const int c = 4 * g + cc;
+            rvv[g & 1][cc] = rv[c];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (4 * t + 3 > c) lv[c][t] = lt[c * 16 + 4 * t + q];
-    }
+            for (int t = 0; t < 4; ++t)
+                if (4 * t + 3 > c) lv[g & 1][cc][t] = lt[c * 16 + 4 * t + q];
+        }
+    };
     auto column = [&](auto ctag) {
         constexpr int c = decltype(ctag)::value;
-        constexpr int qc = c & 3, tc = c >> 2;
-        const double x = quad_bcast<qc>(pr[tc] * rvv[c]);
+        constexpr int qc = c & 3, tc = c >> 2, g = c >> 2;
+        const double x = quad_bcast<qc>(pr[tc] * rvv[g & 1][c & 3]);
         xs[tc] = (q == qc) ? x : xs[tc];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-            if (4 * t + 3 > c) pr[t] = fma(-x, lv[c][t], pr[t]);      // (a finished entry may take junk)
+            if (4 * t + 3 > c) pr[t] = fma(-x, lv[g & 1][c & 3][t], pr[t]);      // (a finished entry may take junk)
     };
+    group(std::integral_constant<int, 0>{});
+    group(std::integral_constant<int, 1>{});
     column(std::integral_constant<int, 0>{});  column(std::integral_constant<int, 1>{});
     column(std::integral_constant<int, 2>{});  column(std::integral_constant<int, 3>{});
+    group(std::integral_constant<int, 2>{});
     column(std::integral_constant<int, 4>{});  column(std::integral_constant<int, 5>{});
     column(std::integral_constant<int, 6>{});  column(std::integral_constant<int, 7>{});
+    group(std::integral_constant<int, 3>{});
     column(std::integral_constant<int, 8>{});  column(std::integral_constant<int, 9>{});
     column(std::integral_constant<int, 10>{}); column(std::integral_constant<int, 11>{});
     column(std::integral_constant<int, 12>{}); column(std::integral_constant<int, 13>{});
@@ -939,9 +949,15 @@ __device__ __forceinline__ void potrf16_step(double (&a)[16], double& l, int r, 
 // Three barriers per panel instead of one per column; the serial chain is 64 register-resident steps.
 // `tbuf`: 4 * POTRF_TB doubles of scratch.  Lo gets the lower triangle, zeros above it.
 constexpr int POTRF_TB = 16 * 16 + 16;
+// `hook(pnl, where)` lets the one-launch Cholesky publish the factor panel by panel while it is being formed:
+// where = 0 just before and 1 just after the barrier that ends phase A of panel pnl, 3 on the wavefronts 1..3 while
+// wavefront 0 factors the 16x16 block of panel pnl (the 16 columns of panel pnl - 1 are final by then).  The
+// launch-per-column kernel passes nothing.
+struct PotrfNoHook { __device__ __forceinline__ void operator()(int, int) const {} };
+template <class Hook = PotrfNoHook>
 __device__ __forceinline__ void potrf64_blk(double* __restrict__ S, double* __restrict__ Lo,
                                             double* __restrict__ tbuf, int* __restrict__ badflag, int bs,
-                                            int dbg = 0) {
+                                            int dbg = 0, Hook hook = Hook()) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // per panel: lt[c*16 + cc] = L16[cc][c] (column c of the panel's diagonal factor), rv[c] = 1 / L16[c][c];
@@ -1002,8 +1018,12 @@ __device__ __forceinline__ void potrf64_blk(double* __restrict__ S, double* __re
                 rv[r] = myrs;
                 if (bad) *badflag = 1;
             }
+        } else {
+            hook(pnl, 3);                                        // the three wavefronts that idle during phase A
         }
+        hook(pnl, 0);
         __syncthreads();
+        hook(pnl, 1);
         if (pnl == NB / 16 - 1) break;
         // ---- B: rows below the diagonal block: x L16^T = p, four lanes per row
         const int nrows = NB - k0 - 16;
@@ -1071,6 +1091,53 @@ __device__ __forceinline__ void trsm64_blk(double* __restrict__ Xs, const double
         }
         __syncthreads();
     }
+}
+
+// trsm64_blk for the one-launch Cholesky: the factor of the block column arrives panel by panel (16 columns at a
+// time) while its owner is still factoring the panels to the right.  `fetch(pnl, 0)` waits for panel pnl and
+// brings its piece (the 16x16 factor copy + reciprocals into tbuf, the rows of the factor below it into Lo) into
+// LDS; it returns false when the launch is being abandoned.  `fetch(pnl, 1)` asks whether the piece has been flagged
+// and `fetch(pnl, 2)` acts on the answer: if so it starts the piece's loads, which then land behind the work on the
+// current panel.  `done(pnl)` runs once the 16 columns of panel pnl of the solution are final (every thread, behind a
+// barrier): the owner publishes them and folds them into what follows while the next piece is on its way.
+// Same arithmetic as trsm64_blk.
+template <class Fetch, class Done>
+__device__ __forceinline__ bool trsm64_stream(double* __restrict__ Xs, const double* __restrict__ Lo,
+                                              const double* __restrict__ tbuf, Fetch fetch, Done done) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll 1
+    for (int pnl = 0; pnl < NB / 16; ++pnl) {
+        const int k0 = 16 * pnl;
+        const double* lt = tbuf + pnl * POTRF_TB;
+        const double* rv = lt + 256;
+        if (!fetch(pnl, 0)) return false;                         // ends with a barrier: the piece is in LDS
+        if (pnl + 1 < NB / 16) fetch(pnl + 1, 1);                 // look for the next piece (the answer lands behind the solve)
+        solve16_quad(Xs, Xs, tid >> 2, k0, lt, rv);
+        if (pnl + 1 < NB / 16) fetch(pnl + 1, 2);                 // if it is there: its loads in flight behind what follows
+        __syncthreads();
+        if (!done(pnl)) return false;
+        if (pnl == NB / 16 - 1) break;
+        {
+            // P(:, 16q ..) -= X_p L(16q .., k0 .. k0+15)^T for the column blocks q > pnl, 16 x 16 pieces
+            const int ncb = NB / 16 - 1 - pnl;
+            const int lr = lane & 15, lq = lane >> 4;
+            for (int b = wave; b < 4 * ncb; b += NTHREADS / 64) {
+                const int bi = b & 3, q = pnl + 1 + (b >> 2);
+                d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const double av = Xs[(16 * bi + lr) * SP + k0 + 4 * kk + lq];
+                    const double bv = Lo[(16 * q + lr) * SP + k0 + 4 * kk + lq];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) Xs[(16 * bi + lq + 4 * rr) * SP + 16 * q + lr] -= acc[rr];
+            }
+        }
+        // (the barrier inside the next fetch separates these writes from the next panel's solve)
+    }
+    return true;
 }
 
 // kc: block column to factor; pend: the rank-64 update from block column kc - 1 is still owed to the
@@ -1333,11 +1400,13 @@ struct CholInst {                                  // one factorisation (one ent
     double* Winv;           // inverses of the diagonal tiles (or null)
     double* logdet;         // scalar result
     int* flags;             // status flags (FLAG_NOT_PD, FLAG_ABORT)
-    int* ready;             // T*T hand-off flags, zero at launch
+    int* ready;             // hand-off flags, zero at launch: T*T tile flags, 4 per block column (the 16-column pieces of
+                            // its factor), 1 per block row (its diagonal tile with the left updates applied)
     double* aux;            // T * CT_AUX doubles
+    double* hand;           // T * 64*64 doubles: diagonal tiles on their way from their accumulators to the chain
     long long* trace;       // development aid: CT_NSTAMP wall-clock stamps per block column from the chain workgroups (or null)
 };
-constexpr int CT_NSTAMP = 8;
+constexpr int CT_NSTAMP = 32;   // 8 stage stamps, then 4 per piece of the streamed panel solve (enter, landed, solved, folded)
 
 // Every shared word is accessed as a GLOBAL agent-scope access (global_load / global_store ... sc1), never through
 // a flat pointer: the pointers arrive inside a struct, which hides their address space from the compiler.
@@ -1497,6 +1566,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void chol_tiles_kernel(CholInst one, c
     const bool has_off = !diagrole || d > 0;
     const int ti = job.i, tj = diagrole ? d - 1 : job.j;          // the off-diagonal tile of this workgroup
     int* abortw = ci.flags + FLAG_ABORT;
+    int* pflags = ci.ready + T * T;                               // 4 per block column: the 16-column pieces of its factor
+    int* hflags = pflags + 4 * T;                                 // 1 per block row: its diagonal tile, left updates applied
     auto blk = [&](int b) { return (int)min((int64_t)NB, m - (int64_t)b * NB); };
     auto at = [&](auto* base, int bi, int bj) { return base + (int64_t)bi * NB * ld + (int64_t)bj * NB; };
     if (stall_test && blockIdx.x == 0) return;                    // test hook: block column 0 is never published
@@ -1505,60 +1576,204 @@ __global__ __launch_bounds__(NTHREADS, 2) void chol_tiles_kernel(CholInst one, c
     };
     stamp(0);                                                     // workgroup started
 
+    // The diagonal tile (d,d) is brought up to date through block column d-2 by ANOTHER workgroup -- the owner of
+    // tile (d,0), which is done with its own tile after the first block column -- and handed over through memory
+    // (hand[d], accumulator layout); the chain workgroup adds only the last update, its own panel block times
+    // itself.  This keeps the chain workgroup's way from "L(d-1,d-2) is there" to its panel solve short.
     acc64_t accO, accD;
     const int mi = blk(ti);
     if (has_off) ct_load_acc(accO, at(ci.src, ti, tj), ld, mi, blk(tj));
-    if (diagrole) ct_load_acc(accD, at(ci.src, d, d), ld, blk(d), blk(d));
+    if (diagrole && d < 2) ct_load_acc(accD, at(ci.src, d, d), ld, blk(d), blk(d));
 
     double run_logdet = 0.0, run_bad = 0.0;
     if (has_off) {
         // ---- rank-64 updates from the block columns left of the tile
         for (int k = 0; k < tj; ++k) {
-            if (!ct_wait(ci.ready + ti * T + k, ci.ready + tj * T + k, abortw, spin_limit, word)) return;
+            // (the block of our own row comes from a workgroup with no diagonal tile to look after, usually the
+            //  earlier of the two: it is on its way into LDS while the other one is still awaited)
+            if (!ct_wait(ci.ready + ti * T + k, nullptr, abortw, spin_limit, word)) return;
             ct_fetch<SQ, false>(R0, at(ci.L, ti, k), ld, mi, NB);
+            if (!ct_wait(ci.ready + tj * T + k, nullptr, abortw, spin_limit, word)) return;
             ct_fetch<SQ, false>(R1, at(ci.L, tj, k), ld, blk(tj), NB);
             __syncthreads();
             ct_update<SQ, SQ>(accO, R0, R1);
-            if (diagrole) ct_update<SQ, SQ>(accD, R0, R0);
         }
         // ---- panel solve against the factor of block column tj:  X L(tj,tj)^T = tile
-        if (!ct_wait(ci.ready + tj * T + tj, nullptr, abortw, spin_limit, word)) return;
-        ct_fetch<SP, true>(R1, at(ci.Ldiag, tj, tj), ld, NB, NB);
-        {
-            const double* ax = ci.aux + (int64_t)tj * CT_AUX;
-            for (int e = tid; e < 4 * POTRF_TB; e += NTHREADS) tbuf[e] = ct_ld(ax + e);
-            run_logdet = ct_ld(ax + 4 * POTRF_TB);
-            run_bad = ct_ld(ax + 4 * POTRF_TB + 1);
-        }
+        // (the tile is staged while the factor is still on its way: R0 is free once every wave is past its products)
+        __syncthreads();
         ct_acc_to_img<false>(R0, accO, NB);
-        __syncthreads();
-        trsm64_blk(R0, R1, tbuf);
-        __syncthreads();
-        ct_publish<false>(R0, at(ci.L, ti, tj), ld, mi, blk(tj));
-        ct_signal(ci.ready + ti * T + tj);
-        if (!diagrole) return;
-        ct_update<SP, SP>(accD, R0, R0);                          // the last update of the diagonal tile: our own panel block
-        __syncthreads();
+        stamp(1);                                                 // updates from the columns further left are in
+        // the factor of block column tj comes in four pieces of 16 columns, each flagged as its owner finishes it
+        const double* ax = ci.aux + (int64_t)tj * CT_AUX;
+        const double* Ljj = at(ci.Ldiag, tj, tj);
+        int* pflag = pflags + 4 * tj;
+        // one piece in registers: its 16x16 factor copy + reciprocals (272 doubles) and the rows of the factor below
+        // it (at most 48 x 16); a wave that found the piece flagged ahead of time already holds its share
+        double pc_t[2], pc_l[3], pc_s[2];
+        bool have = false;
+        int looked = 0;
+        auto load_piece = [&](int pnl) {
+            const int k0 = 16 * pnl;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = tid + q * NTHREADS;
+                pc_t[q] = (e < POTRF_TB) ? ct_ld(ax + pnl * POTRF_TB + e) : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int e = tid + q * NTHREADS;
+                pc_l[q] = (e < (NB - k0 - 16) * 16) ? ct_ld(Ljj + (int64_t)(k0 + 16 + (e >> 4)) * ld + k0 + (e & 15)) : 0.0;
+            }
+            if (pnl == 3) {
+                pc_s[0] = ct_ld(ax + 4 * POTRF_TB);
+                pc_s[1] = ct_ld(ax + 4 * POTRF_TB + 1);
+            }
+        };
+        auto land_piece = [&](int pnl) {
+            const int k0 = 16 * pnl;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = tid + q * NTHREADS;
+                if (e < POTRF_TB) tbuf[pnl * POTRF_TB + e] = pc_t[q];
+            }
+            // rows 16(pnl+1) .. 63 of the factor, columns k0 .. k0+15 (what the update of the columns to the right reads)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int e = tid + q * NTHREADS;
+                if (e < (NB - k0 - 16) * 16) R1[(k0 + 16 + (e >> 4)) * SP + k0 + (e & 15)] = pc_l[q];
+            }
+            if (pnl == 3) { run_logdet = pc_s[0]; run_bad = pc_s[1]; }
+        };
+        auto fetch = [&](int pnl, int mode) -> bool {
+            if (mode == 1) { looked = ct_ldi(pflag + pnl); return true; }            // (uniform within a wave)
+            if (mode == 2) { if (looked != 0) { load_piece(pnl); have = true; } return true; }
+            // (a piece that is already in registers goes to LDS in front of the barrier: nobody reads those
+            //  columns of the images before it)
+            stamp(8 + 4 * pnl + (have ? 0 : 0));
+            if (have) land_piece(pnl);
+            if (__syncthreads_or(have ? 0 : 1)) {
+                if (!ct_wait(pflag + pnl, nullptr, abortw, spin_limit, word)) return false;
+                if (!have) { load_piece(pnl); land_piece(pnl); }
+                __syncthreads();
+            }
+            have = false;
+            stamp(9 + 4 * pnl);
+            if (pnl == 0) stamp(2);                               // the first piece of the previous block column is here
+            if (pnl == 3) stamp(3);                               // ... and the last
+            return true;
+        };
+        // As soon as 16 columns of the solved tile are final they are published, and the owner of a diagonal tile
+        // folds them into the product that is the LAST update of that tile (its own panel block times itself: the
+        // same 64-deep MFMA chain as ct_update, formed from zero in k order and subtracted once, 16 of its 64
+        // steps per panel) -- both while the next piece of the factor is still on its way.
+        double* Lij = at(ci.L, ti, tj);
+        const int mj = blk(tj);
+        d4 p00 = d4{0.0, 0.0, 0.0, 0.0}, p01 = p00, p10 = p00, p11 = p00;
+        auto done = [&](int pnl) -> bool {
+            const int k0 = 16 * pnl;
+            stamp(10 + 4 * pnl);
+            for (int e = tid; e < NB * 16; e += NTHREADS) {
+                const int r = e >> 4, c = k0 + (e & 15);
+                if (r < mi && c < mj) ct_st(Lij + (int64_t)r * ld + c, R0[r * SP + c]);
+            }
+            if (diagrole) {
+                const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+                const int wm = wave >> 1, wn = wave & 1;
+                const double* ap = R0 + (16 * wm + (lane & 15)) * SP + (lane >> 4);
+                const double* bp = R0 + (32 * wn + (lane & 15)) * SP + (lane >> 4);
+#pragma unroll
+                for (int kk = 4 * pnl; kk < 4 * pnl + 4; ++kk) {
+                    const double a0 = ap[4 * kk], a1 = ap[32 * SP + 4 * kk];
+                    const double b0 = bp[4 * kk], b1 = bp[16 * SP + 4 * kk];
+                    p00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, p00, 0, 0, 0);
+                    p01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, p01, 0, 0, 0);
+                    p10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, p10, 0, 0, 0);
+                    p11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, p11, 0, 0, 0);
+                }
+                if (pnl == 2 && d >= 2) {
+                    // the diagonal tile as its accumulator left it (long there by now): requested here, it lands
+                    // while the last piece of the factor is awaited
+                    if (!ct_wait(hflags + d, nullptr, abortw, spin_limit, word)) return false;
+                    const double* hd = ci.hand + (int64_t)d * NB * NB;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) accD[i][j][r] = ct_ld(hd + ((i * 2 + j) * 4 + r) * NTHREADS + tid);
+                }
+            }
+            stamp(11 + 4 * pnl);
+            if (pnl == 3) stamp(4);                               // panel solve done, last columns on their way
+            return true;
+        };
+        if (!trsm64_stream(R0, R1, tbuf, fetch, done)) return;
+        if (!diagrole) {
+            ct_signal(ci.ready + ti * T + tj);
+            if (tj != 0) return;
+            // ---- second life of the owner of tile (i,0): accumulate the diagonal tile (i,i) of its block row
+            // through block column i-2 and hand it to the chain workgroup of that row
+            acc64_t accH;
+            ct_load_acc(accH, at(ci.src, ti, ti), ld, mi, mi);
+            for (int k = 0; k + 1 < ti; ++k) {
+                if (!ct_wait(ci.ready + ti * T + k, nullptr, abortw, spin_limit, word)) return;
+                ct_fetch<SQ, false>(R0, at(ci.L, ti, k), ld, mi, NB);
+                __syncthreads();
+                ct_update<SQ, SQ>(accH, R0, R0);
+            }
+            double* hd = ci.hand + (int64_t)ti * NB * NB;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ct_st(hd + ((i * 2 + j) * 4 + r) * NTHREADS + tid, accH[i][j][r]);
+            ct_signal(hflags + ti);
+            return;
+        }
+        accD[0][0] -= p00; accD[0][1] -= p01; accD[1][0] -= p10; accD[1][1] -= p11;
     }
     // ---- diagonal tile: factor, publish, log-determinant, inverse
     const int bs = blk(d);
     ct_acc_to_img<true>(R1, accD, bs);
     if (tid == 0) *badflag = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the panel block's stores have drained on this wave ...
     __syncthreads();
-    potrf64_blk(R1, R0, tbuf, badflag, bs);                       // factor in R0; ends with a barrier
+    if (has_off && tid == 0) ct_sti(ci.ready + ti * T + tj, 1);   // ... and on every wave: flag it
+    stamp(5);                                                     // diagonal tile up to date and staged
+    // The factor is published in four pieces of 16 columns as potrf64_blk finishes them (rows k0.. of the factor,
+    // lower part, plus that panel's 16x16 copy and reciprocals): piece pnl-1 goes out from the wavefronts that have
+    // nothing to do while wavefront 0 factors the next 16x16 block, and is flagged when that block is done -- by
+    // then its write-through stores have drained -- so the consumers' panel solves run while the panels to the
+    // right are still being factored.
+    double* axd = ci.aux + (int64_t)d * CT_AUX;
+    double* Ldd = at(ci.Ldiag, d, d);
+    int* pflag_d = pflags + 4 * d;
+    auto publish_piece = [&](int pnl, int first, int nthr) {
+        const int k0 = 16 * pnl;
+        for (int e = tid - first; e < (NB - k0) * 16; e += nthr) {
+            const int r = k0 + (e >> 4), c = k0 + (e & 15);
+            if (r < bs && c <= r) ct_st(Ldd + (int64_t)r * ld + c, R0[r * SP + c]);
+        }
+        for (int e = tid - first; e < POTRF_TB; e += nthr) ct_st(axd + pnl * POTRF_TB + e, tbuf[pnl * POTRF_TB + e]);
+    };
+    auto hook = [&](int pnl, int where) {
+        if (where == 3 && pnl > 0) publish_piece(pnl - 1, 64, NTHREADS - 64);
+        else if (where == 0 && pnl > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (where == 1 && pnl > 0 && tid == 0) ct_sti(pflag_d + pnl - 1, 1);          // every wave has drained: flag it
+    };
+    potrf64_blk(R1, R0, tbuf, badflag, bs, 0, hook);              // factor in R0; ends with a barrier
+    stamp(6);                                                     // factored
     double lg = (tid < bs) ? log(R0[tid * SP + tid]) : 0.0;
     for (int off = 32; off > 0; off >>= 1) lg += __shfl_down(lg, off);
     if ((tid & 63) == 0) red[tid >> 6] = lg;
+    publish_piece(3, 0, NTHREADS);
     __syncthreads();
     const double logdet = run_logdet + 2.0 * (red[0] + red[1] + red[2] + red[3]);     // block columns in order
     const double bad = (*badflag != 0 || run_bad != 0.0) ? 1.0 : 0.0;
-    ct_publish<true>(R0, at(ci.Ldiag, d, d), ld, bs, bs);
-    {
-        double* ax = ci.aux + (int64_t)d * CT_AUX;
-        for (int e = tid; e < 4 * POTRF_TB; e += NTHREADS) ct_st(ax + e, tbuf[e]);
-        if (tid == 0) { ct_st(ax + 4 * POTRF_TB, logdet); ct_st(ax + 4 * POTRF_TB + 1, bad); }
-    }
-    ct_signal(ci.ready + d * T + d);
+    if (tid == 0) { ct_st(axd + 4 * POTRF_TB, logdet); ct_st(axd + 4 * POTRF_TB + 1, bad); }
+    ct_signal(pflag_d + 3);
+    stamp(7);                                                     // factor published
     if (d == T - 1 && tid == 0) {
         *ci.logdet = logdet;
         if (bad != 0.0) ci.flags[FLAG_NOT_PD] = 1;
@@ -1944,8 +2159,9 @@ int build_plans(accbpg_dopt* h) {
         if (h->chol_tiles_ok) {
             ACC_HIP(hipMalloc(&h->chol_jobs, sizeof(CholJob) * jobs.size()));
             ACC_HIP(hipMemcpy(h->chol_jobs, jobs.data(), sizeof(CholJob) * jobs.size(), hipMemcpyHostToDevice));
-            ACC_HIP(hipMalloc(&h->chol_ready, sizeof(int) * (size_t)T * T));
-            ACC_HIP(hipMemset(h->chol_ready, 0, sizeof(int) * (size_t)T * T));
+            ACC_HIP(hipMalloc(&h->chol_ready, sizeof(int) * (size_t)(T * T + 5 * T)));
+            ACC_HIP(hipMemset(h->chol_ready, 0, sizeof(int) * (size_t)(T * T + 5 * T)));
+            ACC_HIP(hipMalloc(&h->chol_hand, sizeof(double) * (size_t)T * NB * NB));
             ACC_HIP(hipMalloc(&h->chol_aux, sizeof(double) * (size_t)T * CT_AUX));
             ACC_HIP(hipMalloc(&h->Gbuf, sizeof(double) * (size_t)m * m));
             ACC_HIP(hipMemset(h->Gbuf, 0, sizeof(double) * (size_t)m * m));
@@ -2125,7 +2341,7 @@ static int launch_chol_tiles(accbpg_dopt* h, const double* src, double* A, doubl
     const int T = (int)((m + NB - 1) / NB);
     CholInst ci;
     ci.src = src; ci.L = A; ci.Ldiag = h->Tbuf; ci.Winv = Winv; ci.logdet = h->dscal; ci.flags = h->dflag;
-    ci.ready = h->chol_ready; ci.aux = h->chol_aux; ci.trace = h->chol_trace;
+    ci.ready = h->chol_ready; ci.aux = h->chol_aux; ci.hand = h->chol_hand; ci.trace = h->chol_trace;
     const int dev = (h->device >= 0 && h->device < 64) ? h->device : 0;
     std::lock_guard<std::mutex> lk(g_tiles_mu);
     TilesRing& ring = g_tiles[dev];
@@ -2161,7 +2377,7 @@ int launch_cholesky(accbpg_dopt* h, double* A, double* Winv, const double* xchec
     const bool tiles = chol_tiles_usable(h);
     prof_begin(h, PROF_CHOL);
     zero_scalars_kernel<<<1, (xcheck || tiles) ? 1024 : 64, 0, h->stream>>>(h->dscal, h->dflag, xcheck, h->n,
-                                                                          tiles ? h->chol_ready : nullptr, tiles ? T * T : 0);
+                                                                          tiles ? h->chol_ready : nullptr, tiles ? T * T + 5 * T : 0);
     if (tiles) {
         ACC_TRY(launch_chol_tiles(h, src, A, Winv));
         h->diag_inv_ready = (Winv != nullptr);

@@ -130,6 +130,7 @@ struct accbpg_dopt {
     void* chol_jobs = nullptr;      // CholJob[chol_tiles_grid]
     int* chol_ready = nullptr;      // T*T hand-off flags
     double* chol_aux = nullptr;     // T * CT_AUX doubles
+    double* chol_hand = nullptr;    // T * 64*64 doubles: diagonal tiles handed from their accumulators to the chain
     long long* chol_trace = nullptr;   // development aid: stage stamps of the chain workgroups (null in production)
     double* Gbuf = nullptr;         // m*m: Gram matrix of func_grad when the one-launch Cholesky is in use (kept intact for a redo)
     const double* last_x = nullptr; // arguments of the evaluation in flight (for a redo)

@@ -255,9 +255,10 @@ int accbpg_debug_gram_variant(accbpg_dopt* h, const double* x_dev, int variant, 
  * runs (default 64), bits 24..29 = block columns per outer panel (default 8; 0 leaves it). */
 int accbpg_debug_chol_variant(accbpg_dopt* h, int bits);
 /* Development aid for the one-launch Cholesky (m <= 2048): factor gram_dev once while the workgroups on its critical
- * chain stamp the 100 MHz wall clock at their stage boundaries.  stamps_host: 8 x ceil(m/64) int64 (per block column:
- * workgroup start, left updates in, previous factor seen, staged, panel solve done, diagonal tile up to date,
- * factored, published).  with_inverse != 0 also forms the inverses of the diagonal blocks (as a gradient evaluation). */
+ * chain stamp the 100 MHz wall clock at their stage boundaries.  stamps_host: 32 x ceil(m/64) int64 (per block column:
+ * workgroup start, left updates in, first piece of the previous factor here, last piece here, panel solve done,
+ * diagonal tile staged, factored, published; then per 16-column piece of the streamed panel solve: asked for,
+ * in LDS, solved, folded).  with_inverse != 0 also forms the inverses of the diagonal blocks (as a gradient evaluation). */
 int accbpg_debug_chol_trace(accbpg_dopt* h, const double* gram_dev, int with_inverse, int64_t* stamps_host);
 
 #ifdef __cplusplus

@@ -21,23 +21,26 @@ gram = torch.empty(m, m, dtype=torch.float64, device="cuda")
 f.gram_into(x, gram)
 lib = _lib.load()
 T = (m + 63) // 64
-names = ["start", "left updates in", "prev factor seen", "fetched+staged", "panel solve", "publish+diag update", "potrf", "publish factor"]
-acc_d = np.zeros((T, 8))
+NS = 32
+acc_d = np.zeros((T, NS))
 reps = 20
 for r in range(reps + 2):
-    st = (C.c_int64 * (8 * T))()
+    st = (C.c_int64 * (NS * T))()
     rc = lib.accbpg_debug_chol_trace(f._h, C.c_void_p(gram.data_ptr()), winv, st)
     assert rc == 0, _lib.last_error()
-    a = np.array(st, dtype=np.int64).reshape(T, 8).astype(np.float64) * 0.01     # microseconds
+    a = np.array(st, dtype=np.int64).reshape(T, NS).astype(np.float64) * 0.01     # microseconds
     if r >= 2:
         acc_d += a - a[0, 0]
 a = acc_d / reps
 print("m=%d T=%d: kernel start -> last factor published %.1f us  (%.2f us per block column)" % (m, T, a[-1, 7], a[-1, 7] / T))
-d = np.diff(a[1:], axis=1)          # stages within a chain workgroup (d >= 1)
-for k in range(1, 7):
-    print("  %-22s mean %6.2f us   (min %.2f max %.2f)" % (names[k + 1], d[:, k].mean(), d[:, k].min(), d[:, k].max()))
-hop = a[1:, 2] - a[:-1, 7]
-print("  flag set -> seen by the next chain workgroup: mean %.2f us (min %.2f max %.2f)" % (hop.mean(), hop.min(), hop.max()))
-wait = a[1:, 2] - a[1:, 1]
-print("  chain workgroup idle before the factor arrives: mean %.2f us" % wait.mean())
 print("  per block column (publish to publish): mean %.2f us" % np.diff(a[:, 7]).mean())
+# everything relative to T0 = the moment the PREVIOUS chain workgroup starts its factorisation (its stamp 5)
+rows = range(2, T)
+rel = lambda col: np.mean([a[d, col] - a[d - 1, 5] for d in rows])
+print("  relative to the previous chain workgroup's potrf start (T0):")
+print("    its potrf ends %.2f, its factor is published %.2f" % (np.mean([a[d - 1, 6] - a[d - 1, 5] for d in rows]),
+                                                                 np.mean([a[d - 1, 7] - a[d - 1, 5] for d in rows])))
+print("    this workgroup: left updates in %.2f" % rel(1))
+for p in range(4):
+    print("    piece %d: asked %.2f  in LDS %.2f  solved %.2f  folded %.2f" % (p, rel(8 + 4 * p), rel(9 + 4 * p), rel(10 + 4 * p), rel(11 + 4 * p)))
+print("    diagonal tile staged (own potrf starts) %.2f" % rel(5))
