@@ -42,6 +42,20 @@ _SIGS = {
     "accbpg_vec_count_bad": (C.c_int, [_P, C.c_int64, _P, _P]),
     "accbpg_dopt_gram_lincomb": (C.c_int, [_P, C.c_double, _P, C.c_double, _P, _P]),
     "accbpg_dopt_eval_gram": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_double), _P]),
+    "accbpg_dopt_batch_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int64, C.c_int64, C.c_int64, _P, C.POINTER(_P)]),
+    "accbpg_dopt_batch_destroy": (C.c_int, [_P]),
+    "accbpg_dopt_batch_set_stream": (C.c_int, [_P, _P]),
+    "accbpg_dopt_batch_size": (C.c_int, [_P]),
+    "accbpg_dopt_batch_is_fused": (C.c_int, [_P]),
+    "accbpg_dopt_batch_instance": (_P, [_P, C.c_int]),
+    "accbpg_dopt_batch_func_grad": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), _P,
+                                              C.c_int64, C.POINTER(C.c_int)]),
+    "accbpg_dopt_batch_burg_simplex_div_prox": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double), C.c_double, _P,
+                                                          C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "accbpg_dopt_batch_ls_terms": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                             C.POINTER(C.c_int)]),
+    "accbpg_dopt_batch_axpby": (C.c_int, [_P, C.POINTER(C.c_double), _P, C.POINTER(C.c_double), _P, C.c_int64,
+                                          C.POINTER(C.c_int), _P]),
     "accbpg_vec_workspace_doubles": (C.c_int64, [C.c_int64]),
     "accbpg_burg_simplex_div_prox": (C.c_int, [_P, _P, C.c_double, C.c_double, C.c_int64, _P, _P,
                                                C.POINTER(C.c_int), _P]),

@@ -10,10 +10,213 @@ Every instance owns its D-optimal handle; the length-n kernels keep their scratc
 """
 from __future__ import annotations
 
+import ctypes as C
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 
+import numpy as np
 import torch
+
+from . import _lib
+from .functions import DOptimalObj, _ptr, _stream, to_dev
+
+
+class DOptimalBatch:
+    """K D-optimal objectives of ONE shape evaluated together (C-ABI ``accbpg_dopt_batch_*``): every call covers the
+    active instances with one launch per kernel family and one readback.  Vectors are K x n CUDA tensors, row i =
+    instance i.  The arithmetic of instance i is bit for bit that of ``self.instance(i)`` (a ``DOptimalObj`` on the
+    same handle), so a lock-step batch and a loop over the instances give identical results."""
+
+    def __init__(self, matrices):
+        self._Vs = [to_dev(V)[0] for V in matrices]
+        assert self._Vs, "DOptimalBatch: no instances"
+        self.K = len(self._Vs)
+        self.m, self.n = self._Vs[0].shape
+        for V in self._Vs:
+            assert V.shape == (self.m, self.n) and V.stride(0) == self._Vs[0].stride(0), \
+                "DOptimalBatch: instances must have one shape and one row stride"
+        self.device = self._Vs[0].device
+        self._lib = _lib.load()
+        ptrs = (C.c_void_p * self.K)(*[V.data_ptr() for V in self._Vs])
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self._lib.accbpg_dopt_batch_create(ptrs, self.K, self.m, self.n, self._Vs[0].stride(0), _stream(),
+                                                    C.byref(h))
+        _lib.check(rc, "accbpg_dopt_batch_create")
+        self._h = h
+        self.fused = bool(self._lib.accbpg_dopt_batch_is_fused(h))
+        self.calls = {"value": 0, "grad": 0}        # per instance-evaluation, as DOptimalObj counts them
+        self._views = {}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self._lib.accbpg_dopt_batch_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def instance(self, i):
+        """Instance i as an ordinary objective on the batch's own handle (same plans, same kernels)."""
+        if i not in self._views:
+            sub = C.c_void_p(self._lib.accbpg_dopt_batch_instance(self._h, int(i)))
+            view = DOptimalObj(self._Vs[i], _borrowed=(sub, self))
+            view.overlap_values(False)
+            self._views[i] = view
+        return self._views[i]
+
+    def _mask(self, active):
+        if active is None:
+            return None, list(range(self.K))
+        arr = (C.c_int * self.K)(*[1 if a else 0 for a in active])
+        return arr, [i for i in range(self.K) if active[i]]
+
+    @staticmethod
+    def _raise(status, idx, what, assert_msg):
+        for i in idx:
+            if status[i] != _lib.OK:
+                _lib.check(status[i], "%s (instance %d)" % (what, i), assert_msg)
+
+    def func_grad(self, X, flag=2, active=None):
+        """(f, G): f a length-K NumPy array (entries of inactive instances are nan), G a K x n tensor (rows of
+        inactive instances are left unwritten); flag 0 returns f only, flag 1 G only."""
+        assert X.shape == (self.K, self.n) and X.is_cuda and X.dtype == torch.float64 and X.stride(1) == 1
+        mask, idx = self._mask(active)
+        f = (C.c_double * self.K)(*([float("nan")] * self.K))
+        st = (C.c_int * self.K)()
+        G = torch.empty(self.K, self.n, dtype=torch.float64, device=self.device) if flag != 0 else None
+        with torch.cuda.device(self.device):
+            self._lib.accbpg_dopt_batch_set_stream(self._h, _stream())
+            rc = self._lib.accbpg_dopt_batch_func_grad(self._h, _ptr(X), X.stride(0), mask, int(flag), f, _ptr(G),
+                                                       self.n, st)
+        _lib.check(rc, "accbpg_dopt_batch_func_grad")
+        self._raise(st, idx, "accbpg_dopt_batch_func_grad", "DOptimalObj: x needs to be nonnegative")
+        self.calls["value" if flag == 0 else "grad"] += len(idx)
+        fv = np.array(f[:], dtype=np.float64)
+        if flag == 0:
+            return fv
+        return G if flag == 1 else (fv, G)
+
+    def prox(self, Y, G, Ls, eps, active=None):
+        """Row i: BurgEntropySimplex(eps).div_prox_map(Y[i], G[i], Ls[i]) (Y None: prox_map)."""
+        mask, idx = self._mask(active)
+        Lc = (C.c_double * self.K)(*[float(v) for v in Ls])
+        st = (C.c_int * self.K)()
+        out = torch.empty(self.K, self.n, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            self._lib.accbpg_dopt_batch_set_stream(self._h, _stream())
+            rc = self._lib.accbpg_dopt_batch_burg_simplex_div_prox(self._h, _ptr(Y), _ptr(G), self.n, Lc, float(eps),
+                                                                   _ptr(out), mask, st, None)
+        _lib.check(rc, "accbpg_dopt_batch_burg_simplex_div_prox")
+        self._raise(st, idx, "accbpg_dopt_batch_burg_simplex_div_prox", "Either y or L is not positive.")
+        return out
+
+    def ls_terms(self, G, X, Y, Z=None, Z1=None, active=None):
+        """K x 3 NumPy array: (<g, x-y>, D(x,y), D(z,z1)) per instance."""
+        mask, idx = self._mask(active)
+        out = (C.c_double * (3 * self.K))()
+        st = (C.c_int * self.K)()
+        with torch.cuda.device(self.device):
+            self._lib.accbpg_dopt_batch_set_stream(self._h, _stream())
+            rc = self._lib.accbpg_dopt_batch_ls_terms(self._h, _ptr(G), _ptr(X), _ptr(Y), _ptr(Z), _ptr(Z1), self.n, mask,
+                                                      out, st)
+        _lib.check(rc, "accbpg_dopt_batch_ls_terms")
+        self._raise(st, idx, "accbpg_dopt_batch_ls_terms", "Entries of x or y not positive.")
+        return np.array(out[:], dtype=np.float64).reshape(self.K, 3)
+
+    def axpby(self, a, X, b, Z, active=None):
+        """Row i: a[i]*X[i] + b[i]*Z[i] with NumPy's rounding."""
+        mask, _ = self._mask(active)
+        av = (C.c_double * self.K)(*[float(v) for v in a])
+        bv = (C.c_double * self.K)(*[float(v) for v in b])
+        out = torch.empty(self.K, self.n, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            self._lib.accbpg_dopt_batch_set_stream(self._h, _stream())
+            rc = self._lib.accbpg_dopt_batch_axpby(self._h, av, _ptr(X), bv, _ptr(Z), self.n, mask, _ptr(out))
+        _lib.check(rc, "accbpg_dopt_batch_axpby")
+        return out
+
+
+def ABPG_batch_steps(batch, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=False, restart=False, restart_rule='g'):
+    """ABPG (accbpg/algorithms.py:94-180) on the K instances of a ``DOptimalBatch`` in lock-step: every oracle call,
+    prox and vector pass covers all instances that are still running.  theta, the restart state and the stopping test
+    are kept per instance exactly as the sequential solver keeps them; an instance that stops (D(z+,z) < epsilon)
+    drops out of the later launches.  Yields k after every outer iteration; returns, per instance, ABPG's
+    (x, F, G, T) -- bit-identical to ``ABPG(batch.instance(i), h, L, x0, ...)``."""
+    from .algorithms import solve_theta
+    K, n = batch.K, batch.n
+    t_start = time.time()
+    x0d, as_numpy = to_dev(x0)
+    X = x0d.reshape(1, -1).repeat(K, 1).contiguous() if x0d.dim() == 1 else x0d.clone().contiguous()
+    assert X.shape == (K, n)
+    Z = X.clone()
+    F = np.zeros((K, maxitrs)); G = np.zeros((K, maxitrs)); T = np.zeros((K, maxitrs))
+    theta = [1.0] * K
+    kk = [0] * K
+    active = [True] * K
+    last = [-1] * K                      # last iteration each instance ran
+    result_x = [None] * K
+    eps_prox = getattr(h, "eps", 1e-8)
+    for k in range(maxitrs):
+        if not any(active):
+            break
+        fx = batch.func_grad(X, 0, active)                                  # :135
+        now = time.time() - t_start
+        for i in range(K):
+            if active[i]:
+                F[i, k] = fx[i] + h.extra_Psi(None)
+                T[i, k] = now
+                if theta_eq and kk[i] > 0:                                  # :142-145
+                    theta[i] = solve_theta(theta[i], gamma)
+                else:
+                    theta[i] = gamma / (kk[i] + gamma)
+        one_m = [1 - t for t in theta]
+        Y = batch.axpby(one_m, X, theta, Z, active)                         # :147
+        Gr = batch.func_grad(Y, 1, active)                                  # :148
+        Zn = batch.prox(Z, Gr, [t ** (gamma - 1) * L for t in theta], eps_prox, active)    # :149
+        Xn = batch.axpby(one_m, X, theta, Zn, active)                       # :150
+        terms = batch.ls_terms(None, Xn, Y, Zn, Z, active)                  # :153-154
+        rest = None
+        if restart and restart_rule == 'g' and k > 0:
+            rest = batch.ls_terms(Gr, Xn, X, None, None, active)[:, 0]      # <g, x - x_1>, :168
+        Znext = Zn
+        for i in range(K):
+            if not active[i]:
+                continue
+            dxy, dzz = terms[i, 1], terms[i, 2]
+            G[i, k] = dxy / dzz / theta[i] ** gamma                         # :155
+            last[i] = k
+            kk[i] += 1
+            if restart and k > 0:                                           # :165-171
+                if (restart_rule == 'f' and F[i, k] > F[i, k - 1]) or (restart_rule == 'g' and rest[i] > 0):
+                    theta[i] = 1.0
+                    kk[i] = 0
+                    if Znext is Zn:
+                        Znext = Zn.clone()
+                    Znext[i] = Xn[i]
+            if dzz < epsilon:                                               # :174
+                active[i] = False
+                result_x[i] = Xn[i].clone()
+        X, Z = Xn, Znext
+        yield k
+    out = []
+    for i in range(K):
+        xi = result_x[i] if result_x[i] is not None else X[i].clone()
+        xi = xi.cpu().numpy() if as_numpy else xi
+        out.append((xi, F[i, :last[i] + 1].copy(), G[i, :last[i] + 1].copy(), T[i, :last[i] + 1].copy()))
+    return out
+
+
+def ABPG_batch(batch, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=False, restart=False, restart_rule='g'):
+    """Drain ``ABPG_batch_steps``: list of (x, F, G, T), one per instance."""
+    gen = ABPG_batch_steps(batch, h, L, x0, gamma, maxitrs, epsilon, theta_eq, restart, restart_rule)
+    while True:
+        try:
+            next(gen)
+        except StopIteration as stop:
+            return stop.value
 
 
 def solve_instances(make_problem, num_instances, solver, world=1, rank=0, threads=None, concurrent=True,

@@ -29,14 +29,15 @@ using namespace accbpg;
 extern "C" int accbpg_abi_version(void) { return 1; }
 extern "C" const char* accbpg_last_error(void) { return g_err; }
 
-static int dopt_init(accbpg_dopt* h) {
+namespace accbpg {
+int dopt_init(accbpg_dopt* h) {
     const int64_t m = h->m, n = h->n;
     ACC_HIP(hipGetDevice(&h->device));
     hipDeviceProp_t prop;
     ACC_HIP(hipGetDeviceProperties(&prop, h->device));
     h->num_cu = prop.multiProcessorCount;
-    h->big = (m >= 768);
     h->vec_ok = ((reinterpret_cast<uintptr_t>(h->V) & 15) == 0) && ((h->ldv & 1) == 0);
+    h->big = (m >= 768) || (h->force_big && h->vec_ok && m >= 256 && (m % 256 == 0) && (n % 128 == 0));
     const size_t mm = sizeof(double) * (size_t)m * (size_t)m;
     ACC_HIP(hipMalloc(&h->Lbuf, mm));
     ACC_HIP(hipMalloc(&h->Wbuf, mm));
@@ -44,15 +45,20 @@ static int dopt_init(accbpg_dopt* h) {
     ACC_HIP(hipMemset(h->Lbuf, 0, mm));
     ACC_HIP(hipMemset(h->Wbuf, 0, mm));     // the upper triangle of W must read as zero
     ACC_HIP(hipMemset(h->Tbuf, 0, mm));
-    ACC_HIP(hipMalloc(&h->dscal, sizeof(double) * 24));        // 16 scalars, then the status flags: one readback
+    if (h->dscal_ext) {
+        h->dscal = h->dscal_ext;                                // a slice of the batch's array (zeroed by the batch)
+    } else {
+        ACC_HIP(hipMalloc(&h->dscal, sizeof(double) * 24));     // 16 scalars, then the status flags: one readback
+        ACC_HIP(hipMemset(h->dscal, 0, sizeof(double) * 24));
+    }
     h->dflag = reinterpret_cast<int*>(h->dscal + 16);
-    ACC_HIP(hipMemset(h->dscal, 0, sizeof(double) * 24));
     ACC_HIP(hipHostMalloc(&h->hpin, sizeof(double) * 32, hipHostMallocDefault));
     const int64_t vws = std::max<int64_t>(vec_ws_doubles(n), 64 * n);
     ACC_HIP(hipMalloc(&h->vws, sizeof(double) * (size_t)vws));
     ACC_HIP(hipEventCreate(&h->ev_done));
     return build_plans(h);
 }
+}  // namespace accbpg
 
 extern "C" int accbpg_dopt_create(const double* V_dev, int64_t m, int64_t n, int64_t ldv, void* stream,
                                   accbpg_dopt** out, int is_shard) {
@@ -79,7 +85,8 @@ extern "C" int accbpg_dopt_create(const double* V_dev, int64_t m, int64_t n, int
 extern "C" int accbpg_dopt_destroy(accbpg_dopt* h) {
     if (!h) return ACCBPG_OK;
     hipFree(h->Lbuf); hipFree(h->Wbuf); hipFree(h->Tbuf); hipFree(h->slabs); hipFree(h->tiles); hipFree(h->wg_ranges); hipFree(h->gram_cstart); hipFree(h->gram_contrib);
-    hipFree(h->dscal); hipFree(h->vws); hipFree(h->xbuf); hipFree(h->ops); hipFree(h->chol_op); hipFree(h->red); hipFree(h->Pbuf);
+    if (!h->dscal_ext) hipFree(h->dscal);
+    hipFree(h->vws); hipFree(h->xbuf); hipFree(h->ops); hipFree(h->chol_op); hipFree(h->red); hipFree(h->Pbuf);
     hipFree(h->fw_x); hipFree(h->fw_w); hipFree(h->fw_H); hipFree(h->fw_hv);
     hipFree(h->chol_jobs); hipFree(h->chol_ready); hipFree(h->chol_aux); hipFree(h->chol_hand); hipFree(h->Gbuf);
     if (h->hpin) hipHostFree(h->hpin);

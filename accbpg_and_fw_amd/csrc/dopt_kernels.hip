@@ -146,7 +146,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_kernel(
 // GV (timing ablations only): bit 0 = no loads inside the k-loop, bit 1 = no wait + barrier,
 // bit 2 = no fragment reads, bit 3 = barrier without the vmcnt wait, bit 4 = half of the fragment reads.
 template <class T, int GV = 0>
-__global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_glds_kernel(
+__device__ __forceinline__ void gram_streamk_glds_body(
     const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n, const double* __restrict__ x,
     const TileRC* __restrict__ tiles, const int64_t* __restrict__ wg_ranges, int64_t kiters, int nslot,
     double* __restrict__ slabs,
@@ -302,12 +302,34 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_glds_kernel(
     }
 }
 
+template <class T, int GV = 0>
+__global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_glds_kernel(
+    const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n, const double* __restrict__ x,
+    const TileRC* __restrict__ tiles, const int64_t* __restrict__ wg_ranges, int64_t kiters, int nslot,
+    double* __restrict__ slabs,
+    double* __restrict__ G, int64_t ldg) {
+    gram_streamk_glds_body<T, GV>(V, ldv, m, n, x, tiles, wg_ranges, kiters, nslot, slabs, G, ldg);
+}
+// The same kernel over the ACTIVE instances of a batch of same-shaped problems (blockIdx.y picks the instance;
+// the tile list and the stream-K ranges are shared, matrix / slabs / result come from the instance table, x from
+// row `instance` of a K x n array).
+template <class T>
+__global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_glds_batch_kernel(
+    const BatchInst* __restrict__ bt, BatchAct act, int64_t ldv, int64_t m, int64_t n, const double* __restrict__ xbase,
+    int64_t ldx, const TileRC* __restrict__ tiles, const int64_t* __restrict__ wg_ranges, int64_t kiters, int nslot,
+    int64_t ldg) {
+    const int inst = act.idx[blockIdx.y];
+    const BatchInst bi = bt[inst];
+    gram_streamk_glds_body<T, 0>(bi.V, ldv, m, n, xbase + (int64_t)inst * ldx, tiles, wg_ranges, kiters, nslot, bi.slabs,
+                                 bi.gram, ldg);
+}
+
 // grid = ntiles * 2 * T::MI * FIX_PJ: workgroup (entry, half, part, jq) sums column-fragment group jq of
 // fragment row `part` of the slabs of one tile (entry = a tile, or half 0/1 of a pair of dual diagonal
 // tiles): many small workgroups, because the pass is bound by HBM latency, not by 72 CUs' worth of adds
 constexpr int FIX_PJ = 4;
 template <class T>
-__global__ __launch_bounds__(NTHREADS, 2) void gram_fixup_kernel(
+__device__ __forceinline__ void gram_fixup_body(
     const TileRC* __restrict__ tiles, const int32_t* __restrict__ cstart, const int32_t* __restrict__ contrib,
     int nslot, const double* __restrict__ slabs, double* __restrict__ G, int64_t ldg, int64_t m) {
     constexpr int JW = (T::NI + FIX_PJ - 1) / FIX_PJ;
@@ -365,6 +387,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gram_fixup_kernel(
             }
         }
     }
+}
+
+template <class T>
+__global__ __launch_bounds__(NTHREADS, 2) void gram_fixup_kernel(
+    const TileRC* __restrict__ tiles, const int32_t* __restrict__ cstart, const int32_t* __restrict__ contrib,
+    int nslot, const double* __restrict__ slabs, double* __restrict__ G, int64_t ldg, int64_t m) {
+    gram_fixup_body<T>(tiles, cstart, contrib, nslot, slabs, G, ldg, m);
+}
+template <class T>
+__global__ __launch_bounds__(NTHREADS, 2) void gram_fixup_batch_kernel(
+    const BatchInst* __restrict__ bt, BatchAct act, const TileRC* __restrict__ tiles, const int32_t* __restrict__ cstart,
+    const int32_t* __restrict__ contrib, int nslot, int64_t ldg, int64_t m) {
+    const BatchInst bi = bt[act.idx[blockIdx.y]];
+    gram_fixup_body<T>(tiles, cstart, contrib, nslot, bi.slabs, bi.gram, ldg, m);
 }
 
 // =========================================================================================
@@ -466,7 +502,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void colnorm_kernel(
 
 // Direct-to-LDS version of the gradient kernel for interior sizes.
 template <class T>
-__global__ __launch_bounds__(NTHREADS, 1) void colnorm_glds_kernel(
+__device__ __forceinline__ void colnorm_glds_body(
     const double* __restrict__ W, int64_t ldw, const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n,
     double* __restrict__ out, double sign) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -575,14 +611,28 @@ __global__ __launch_bounds__(NTHREADS, 1) void colnorm_glds_kernel(
     }
 }
 
+template <class T>
+__global__ __launch_bounds__(NTHREADS, 1) void colnorm_glds_kernel(
+    const double* __restrict__ W, int64_t ldw, const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n,
+    double* __restrict__ out, double sign) {
+    colnorm_glds_body<T>(W, ldw, V, ldv, m, n, out, sign);
+}
+template <class T>
+__global__ __launch_bounds__(NTHREADS, 1) void colnorm_glds_batch_kernel(
+    const BatchInst* __restrict__ bt, BatchAct act, int64_t ldw, int64_t ldv, int64_t m, int64_t n,
+    double* __restrict__ outbase, int64_t ldo, double sign) {
+    const int inst = act.idx[blockIdx.y];
+    const BatchInst bi = bt[inst];
+    colnorm_glds_body<T>(bi.Wbuf, ldw, bi.V, ldv, m, n, outbase + (int64_t)inst * ldo, sign);
+}
+
 // =========================================================================================
 // Batched small GEMM on the 64x64 tile: C = alpha*A*op(B) + beta*C for a table of products.
 // grid = (tiles_n, tiles_m, nops).  Used by the Cholesky trailing update and the inverse merges.
 // =========================================================================================
 template <class T>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_ops_kernel(const GemmOp* __restrict__ ops) {
+__device__ __forceinline__ void gemm_ops_body(const GemmOp op) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const GemmOp op = ops[blockIdx.z];
     const int64_t row0 = (int64_t)blockIdx.y * T::BM, col0 = (int64_t)blockIdx.x * T::BN;
     if (row0 >= op.M || col0 >= op.N) return;
     if (op.lower_only && col0 > row0 + T::BM - 1) return;
@@ -618,9 +668,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_ops_kernel(const GemmOp* __r
     t.store_C(op.C, op.ldc, row0, col0, op.M, op.N, op.alpha, op.beta, op.lower_only != 0);
 }
 
+template <class T>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_ops_kernel(const GemmOp* __restrict__ ops) {
+    gemm_ops_body<T>(ops[blockIdx.z]);
+}
+// products of the ACTIVE instances of a batch: `ops` holds the op tables of all instances one after the other
+// (`per_inst` ops each, the same stage of every instance at the same offset)
+template <class T>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_ops_batch_kernel(const GemmOp* __restrict__ ops, int per_inst, int begin,
+                                                                    int count, BatchAct act) {
+    const int a = blockIdx.z / count, o = blockIdx.z - a * count;
+    gemm_ops_body<T>(ops[(int64_t)act.idx[a] * per_inst + begin + o]);
+}
+
 // split-K reduction: C = sum of the ns partial products (fixed order)
-__global__ __launch_bounds__(256) void gemm_reduce_kernel(const RedOp* __restrict__ reds) {
-    const RedOp r = reds[blockIdx.y];
+__device__ __forceinline__ void gemm_reduce_body(const RedOp r) {
     const int64_t total = (int64_t)r.M * r.N;
     const int64_t stride = (int64_t)gridDim.x * 256 * 2;
     for (int64_t e = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x); e < total; e += stride) {
@@ -633,6 +695,12 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const RedOp* __restric
         const int64_t row = e / r.N, col = e - row * r.N;
         *reinterpret_cast<double2*>(r.C + row * r.ldc + col) = acc;
     }
+}
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const RedOp* __restrict__ reds) { gemm_reduce_body(reds[blockIdx.y]); }
+__global__ __launch_bounds__(256) void gemm_reduce_batch_kernel(const RedOp* __restrict__ reds, int per_inst, int begin, int count,
+                                                               BatchAct act) {
+    const int a = blockIdx.y / count, o = blockIdx.y - a * count;
+    gemm_reduce_body(reds[(int64_t)act.idx[a] * per_inst + begin + o]);
 }
 
 // same loop on the big tile, single product (unit-test hook and large merges)
@@ -1392,20 +1460,6 @@ constexpr int CT_AUX = 4 * POTRF_TB + 8;          // per block column: the four 
 constexpr int CT_LDS_DOUBLES = 2 * NB * SQ + 4 * POTRF_TB + 16;
 constexpr int CT_LDS_BYTES = CT_LDS_DOUBLES * 8;  // 76.9 KB: two workgroups per CU
 
-struct CholJob { int i, j; };                     // i == j: owner of the diagonal tile (and of (i, i-1))
-struct CholInst {                                  // one factorisation (one entry per instance of a batched launch)
-    const double* src;      // matrix to factor (lower triangle significant), leading dimension ld
-    double* L;              // off-diagonal tiles of the factor (may be src: in place)
-    double* Ldiag;          // diagonal tiles of the factor
-    double* Winv;           // inverses of the diagonal tiles (or null)
-    double* logdet;         // scalar result
-    int* flags;             // status flags (FLAG_NOT_PD, FLAG_ABORT)
-    int* ready;             // hand-off flags, zero at launch: T*T tile flags, 4 per block column (the 16-column pieces of
-                            // its factor), 1 per block row (its diagonal tile with the left updates applied)
-    double* aux;            // T * CT_AUX doubles
-    double* hand;           // T * 64*64 doubles: diagonal tiles on their way from their accumulators to the chain
-    long long* trace;       // development aid: CT_NSTAMP wall-clock stamps per block column from the chain workgroups (or null)
-};
 constexpr int CT_NSTAMP = 32;   // 8 stage stamps, then 4 per piece of the streamed panel solve (enter, landed, solved, folded)
 
 // Every shared word is accessed as a GLOBAL agent-scope access (global_load / global_store ... sc1), never through
@@ -1549,7 +1603,7 @@ __device__ __forceinline__ void ct_update(acc64_t& acc, const double* __restrict
 
 __global__ __launch_bounds__(NTHREADS, 2) void chol_tiles_kernel(CholInst one, const CholInst* __restrict__ table,
                                                                 const CholJob* __restrict__ jobs, int64_t ld, int64_t m,
-                                                                int T, long long spin_limit, int stall_test) {
+                                                                int T, long long spin_limit, int stall_test, BatchAct act) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* R0 = lds;                           // operand image (stride SQ) / tile image (stride SP)
     double* R1 = R0 + NB * SQ;                  // operand image / factor image
@@ -1558,7 +1612,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void chol_tiles_kernel(CholInst one, c
     int* badflag = word + 2;
     double* red = tbuf + 4 * POTRF_TB + 8;
 
-    const CholInst ci = (table != nullptr) ? table[blockIdx.y] : one;
+    const CholInst ci = (table != nullptr) ? table[act.idx[blockIdx.y]] : one;
     const CholJob job = jobs[blockIdx.x];
     const int tid = threadIdx.x;
     const bool diagrole = (job.i == job.j);
@@ -1841,6 +1895,23 @@ __global__ __launch_bounds__(1024) void zero_scalars_kernel(double* dscal, int* 
     if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) dflag[FLAG_NEG_X] = 1;
 }
 
+// the same reset for the active instances of a batch (one workgroup per instance)
+__global__ __launch_bounds__(1024) void zero_scalars_batch_kernel(const BatchInst* __restrict__ bt, BatchAct act,
+                                                                const double* __restrict__ xbase, int64_t ldx, int64_t n,
+                                                                int nready) {
+    const int inst = act.idx[blockIdx.x];
+    const BatchInst bi = bt[inst];
+    if (threadIdx.x < 8) __hip_atomic_store(bi.dscal + threadIdx.x, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 8) bi.dflag[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < nready; i += blockDim.x) bi.chol_ready[i] = 0;
+    if (xbase == nullptr) return;
+    const double* x = xbase + (int64_t)inst * ldx;
+    bool bad = false;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
+        if (!(x[i] >= 0.0)) bad = true;
+    if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) bi.dflag[FLAG_NEG_X] = 1;
+}
+
 __global__ void set_op_kernel(GemmOp* slot, GemmOp op) { *slot = op; }
 
 // fp64 MFMA peak: every wave issues `iters` x 8 independent-accumulator MFMAs (inline asm keeps the
@@ -1919,6 +1990,7 @@ int build_plans(accbpg_dopt* h) {
     h->ntiles = (int)tl.size();
     const int64_t total = (int64_t)h->ntiles * h->kiters;
     int grid = h->big ? h->num_cu : 2 * h->num_cu;
+    if (h->gram_grid_cap > 0 && grid > h->gram_grid_cap) grid = h->gram_grid_cap;   // one instance of a batch: its share of the chip
     if (grid > total) grid = (int)total;
     if (grid < h->ntiles && total / h->ntiles < 8) grid = h->ntiles;   // tiny K: one tile per workgroup
     int64_t per = (total + grid - 1) / grid;
@@ -2139,6 +2211,7 @@ int build_plans(accbpg_dopt* h) {
         ACC_HIP(hipMalloc(&h->ops, sizeof(GemmOp) * h->ops_host.size()));
         ACC_HIP(hipMemcpy(h->ops, h->ops_host.data(), sizeof(GemmOp) * h->ops_host.size(), hipMemcpyHostToDevice));
     }
+    h->red_host = reds;
     if (!reds.empty()) {
         ACC_HIP(hipMalloc(&h->red, sizeof(RedOp) * reds.size()));
         ACC_HIP(hipMemcpy(h->red, reds.data(), sizeof(RedOp) * reds.size(), hipMemcpyHostToDevice));
@@ -2357,7 +2430,7 @@ static int launch_chol_tiles(accbpg_dopt* h, const double* src, double* A, doubl
         }
     }
     chol_tiles_kernel<<<dim3(h->chol_tiles_grid, 1), NTHREADS, CT_LDS_BYTES, h->stream>>>(
-        ci, nullptr, reinterpret_cast<const CholJob*>(h->chol_jobs), m, m, T, h->chol_spin_limit, h->chol_stall_test);
+        ci, nullptr, reinterpret_cast<const CholJob*>(h->chol_jobs), m, m, T, h->chol_spin_limit, h->chol_stall_test, BatchAct{});
     ACC_HIP(hipGetLastError());
     {
         const int slot = (int)(ring.issued % TILES_RING);
@@ -2456,6 +2529,94 @@ int launch_colnorm(accbpg_dopt* h, const double* W, double* out, double sign) {
         else colnorm_launch_t<TileSmall<true, true>>(h, W, out, sign, vw);
     }
     prof_end(h, PROF_GRAD);
+    ACC_HIP(hipGetLastError());
+    return ACCBPG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Batched launches: the active instances of a batch of same-shaped problems, one launch per kernel family.
+// Only the interior big-tile path (m a multiple of 256, n of 128, 16-byte aligned rows) is batched; the caller
+// evaluates other shapes instance by instance.
+// ---------------------------------------------------------------------------------------------------------
+int launch_gram_batch(accbpg_dopt_batch* b, const BatchAct& act, const double* xbase, int64_t ldx) {
+    using T = TileBig<false, false>;
+    accbpg_dopt* h0 = b->inst[0];
+    static bool lds_set = false;
+    if (!lds_set) {
+        ACC_TRY(set_lds(gram_streamk_glds_batch_kernel<T>, T::G_LDS_BYTES));
+        lds_set = true;
+    }
+    gram_streamk_glds_batch_kernel<T><<<dim3(h0->gram_grid, act.n), NTHREADS, T::G_LDS_BYTES, b->stream>>>(
+        b->table, act, h0->ldv, h0->m, h0->n, xbase, ldx, h0->tiles, h0->wg_ranges, h0->kiters, h0->gram_nslot, h0->m);
+    gram_fixup_batch_kernel<T><<<dim3(h0->ntiles * 2 * T::MI * FIX_PJ, act.n), NTHREADS, 0, b->stream>>>(
+        b->table, act, h0->tiles, h0->gram_cstart, h0->gram_contrib, h0->gram_nslot, h0->m, h0->m);
+    ACC_HIP(hipGetLastError());
+    return ACCBPG_OK;
+}
+
+int launch_cholesky_batch(accbpg_dopt_batch* b, const BatchAct& act, bool with_inverse, const double* xbase, int64_t ldx) {
+    accbpg_dopt* h0 = b->inst[0];
+    const int64_t m = h0->m;
+    const int T = (int)((m + NB - 1) / NB);
+    zero_scalars_batch_kernel<<<act.n, 1024, 0, b->stream>>>(b->table, act, xbase, ldx, h0->n, T * T + 5 * T);
+    const int dev = (b->device >= 0 && b->device < 64) ? b->device : 0;
+    const int grid_all = h0->chol_tiles_grid * act.n;
+    std::lock_guard<std::mutex> lk(g_tiles_mu);
+    TilesRing& ring = g_tiles[dev];
+    {
+        int gmax = grid_all;
+        for (int i = 0; i < TILES_RING; ++i) gmax = std::max(gmax, ring.grid[i]);
+        int together = (2 * h0->num_cu) / std::max(1, gmax);
+        if (together > TILES_RING - 1) together = TILES_RING - 1;
+        if (together < 1) together = 1;
+        for (long long back = together; back <= TILES_RING && back <= ring.issued; ++back) {
+            const int slot = (int)((ring.issued - back) % TILES_RING);
+            if (ring.ev[slot] && ring.stream[slot] != b->stream) ACC_HIP(hipStreamWaitEvent(b->stream, ring.ev[slot], 0));
+        }
+    }
+    chol_tiles_kernel<<<dim3(h0->chol_tiles_grid, act.n), NTHREADS, CT_LDS_BYTES, b->stream>>>(
+        CholInst{}, b->chol_table[with_inverse ? 1 : 0], reinterpret_cast<const CholJob*>(h0->chol_jobs), m, m, T,
+        h0->chol_spin_limit, 0, act);
+    ACC_HIP(hipGetLastError());
+    {
+        const int slot = (int)(ring.issued % TILES_RING);
+        if (!ring.ev[slot]) ACC_HIP(hipEventCreateWithFlags(&ring.ev[slot], hipEventDisableTiming));
+        ACC_HIP(hipEventRecord(ring.ev[slot], b->stream));
+        ring.stream[slot] = b->stream;
+        ring.grid[slot] = grid_all;
+        ++ring.issued;
+    }
+    return ACCBPG_OK;
+}
+
+int launch_trtri_batch(accbpg_dopt_batch* b, const BatchAct& act) {
+    accbpg_dopt* h0 = b->inst[0];
+    for (const accbpg_dopt::MergeStage& st : h0->merge_stages) {
+        const int count = st.end - st.begin;
+        if (count <= 0) continue;
+        if (st.kind == 0) {
+            dim3 grid((st.maxn + 63) / 64, (st.maxm + 63) / 64, count * act.n);
+            gemm_ops_batch_kernel<TileSmall<true>><<<grid, NTHREADS, TileSmall<true>::LDS_BYTES, b->stream>>>(
+                b->ops_all, b->ops_per_inst, st.begin, count, act);
+        } else {
+            int gx = (int)std::min<int64_t>(1024, ((int64_t)st.maxm / 2 + 255) / 256);
+            gemm_reduce_batch_kernel<<<dim3(gx, count * act.n), 256, 0, b->stream>>>(b->red_all, b->red_per_inst, st.begin, count, act);
+        }
+    }
+    ACC_HIP(hipGetLastError());
+    return ACCBPG_OK;
+}
+
+int launch_colnorm_batch(accbpg_dopt_batch* b, const BatchAct& act, double* gbase, int64_t ldg, double sign) {
+    using T = TileBig<true, false>;
+    accbpg_dopt* h0 = b->inst[0];
+    static bool lds_set = false;
+    if (!lds_set) {
+        ACC_TRY(set_lds(colnorm_glds_batch_kernel<T>, T::G_LDS_BYTES + 4 * T::BN * 8));
+        lds_set = true;
+    }
+    colnorm_glds_batch_kernel<T><<<dim3((unsigned)(h0->n / T::BN), act.n), NTHREADS, T::G_LDS_BYTES + 4 * T::BN * 8, b->stream>>>(
+        b->table, act, h0->m, h0->ldv, h0->m, h0->n, gbase, ldg, sign);
     ACC_HIP(hipGetLastError());
     return ACCBPG_OK;
 }

@@ -55,6 +55,40 @@ struct TileRC {
     int32_t d1 = -1, d2 = -1;
 };
 
+// A batch of same-shaped instances evaluated by ONE launch per kernel family (blockIdx.y = position among the
+// active instances): the per-instance pointers live in a device table, the active set travels as a kernel argument.
+constexpr int BATCH_MAX = 32;
+struct BatchAct {
+    int n = 0;
+    int idx[BATCH_MAX] = {};
+};
+struct BatchInst {
+    const double* V;        // design matrix of the instance
+    double* slabs;          // stream-K slabs
+    double* gram;           // Gram matrix target of func_grad
+    double* Lbuf;
+    double* Wbuf;
+    double* Tbuf;
+    double* dscal;          // scalars + status flags of the instance (slice of one array for the whole batch)
+    int* dflag;
+    int* chol_ready;
+};
+
+struct CholJob { int i, j; };                     // i == j: owner of the diagonal tile (and of (i, i-1))
+struct CholInst {                                  // one factorisation (one entry per instance of a batched launch)
+    const double* src;      // matrix to factor (lower triangle significant), leading dimension ld
+    double* L;              // off-diagonal tiles of the factor (may be src: in place)
+    double* Ldiag;          // diagonal tiles of the factor
+    double* Winv;           // inverses of the diagonal tiles (or null)
+    double* logdet;         // scalar result
+    int* flags;             // status flags (FLAG_NOT_PD, FLAG_ABORT)
+    int* ready;             // hand-off flags, zero at launch: T*T tile flags, 4 per block column (the 16-column pieces of
+                            // its factor), 1 per block row (its diagonal tile with the left updates applied)
+    double* aux;            // T * CT_AUX doubles
+    double* hand;           // T * 64*64 doubles: diagonal tiles on their way from their accumulators to the chain
+    long long* trace;       // development aid: CT_NSTAMP wall-clock stamps per block column from the chain workgroups (or null)
+};
+
 constexpr int NB = 64;          // Cholesky / inverse block size
 constexpr int FLAG_NOT_PD = 0;  // index into the device flag array
 constexpr int FLAG_NEG_X = 1;
@@ -82,6 +116,10 @@ struct accbpg_dopt {
     int device = 0;
     int num_cu = 256;
     bool big = false;           // use the 256x128 tile for Gram / gradient products
+    // set before the plans are built when the handle is one instance of a batch (accbpg_dopt_batch_create)
+    bool force_big = false;     // 256x128 tiles also below m = 768 (interior shapes only)
+    int gram_grid_cap = 0;      // stream-K workgroups of this instance's Gram launch (0: the whole chip)
+    double* dscal_ext = nullptr;   // scalars + flags live in this slice of the batch's array instead of an own allocation
     bool vec_ok = false;        // V rows are 16-byte aligned
 
     double* Lbuf = nullptr;     // m*m : Gram matrix, then its Cholesky factor (lower)
@@ -102,6 +140,7 @@ struct accbpg_dopt {
 
     accbpg::GemmOp* ops = nullptr;            // device op table of the inverse merges
     std::vector<accbpg::GemmOp> ops_host;
+    std::vector<accbpg::RedOp> red_host;
     // launch list of the inverse merges: kind 0 = products ops[begin, end), kind 1 = partial-sum reductions red[begin, end)
     struct MergeStage { int kind, begin, end, maxm, maxn; };
     std::vector<MergeStage> merge_stages;
@@ -141,9 +180,39 @@ struct accbpg_dopt {
     accbpg::ProfSlot prof[accbpg::PROF_COUNT];
 };
 
+// A batch of same-shaped D-optimal instances evaluated together (accbpg_dopt_batch_*)
+struct accbpg_dopt_batch {
+    int K = 0;
+    std::vector<accbpg_dopt*> inst;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    bool fast = false;                      // one launch per kernel family over the active instances
+    accbpg::BatchInst* table = nullptr;     // device, K entries
+    accbpg::CholInst* chol_table[2] = {nullptr, nullptr};   // device, K entries each: without / with diagonal-block inverses
+    accbpg::GemmOp* ops_all = nullptr;      // device: the merge op tables of all instances, instance after instance
+    accbpg::RedOp* red_all = nullptr;
+    int ops_per_inst = 0, red_per_inst = 0;
+    double* dscal_all = nullptr;            // device, K * 24 doubles (scalars + flags of every instance)
+    double* hpin = nullptr;                 // pinned mirror
+    // scratch of the batched length-n kernels (vec_kernels.hip), allocated on first use
+    int* vflags = nullptr;                  // K * 8 ints: status flags + {bisection, newton} of the prox
+    double* vout = nullptr;                 // K * 4 doubles: reduction results
+    double* vpart = nullptr;                // K * 4 * 1024 doubles: reduction partials
+    double* vgg = nullptr;                  // K * n doubles: gg of the prox when it does not fit in registers
+    double* vpin = nullptr;                 // pinned mirror (K * 8 doubles)
+};
+struct BatchVals { double v[accbpg::BATCH_MAX]; };          // one scalar per instance, as a kernel argument
+
 namespace accbpg {
 
+// batched launches over the active instances (dopt_kernels.hip)
+int launch_gram_batch(accbpg_dopt_batch* b, const BatchAct& act, const double* xbase, int64_t ldx);
+int launch_cholesky_batch(accbpg_dopt_batch* b, const BatchAct& act, bool with_inverse, const double* xbase, int64_t ldx);
+int launch_trtri_batch(accbpg_dopt_batch* b, const BatchAct& act);
+int launch_colnorm_batch(accbpg_dopt_batch* b, const BatchAct& act, double* gbase, int64_t ldg, double sign);
+
 // dopt_kernels.hip
+int dopt_init(accbpg_dopt* h);
 int launch_gram(accbpg_dopt* h, const double* x, double* gram);
 int launch_cholesky(accbpg_dopt* h, double* A /* m*m, factor goes here */, double* Winv = nullptr /* diagonal-block inverses */,
                     const double* xcheck = nullptr /* x >= 0 check folded into the reset launch */,

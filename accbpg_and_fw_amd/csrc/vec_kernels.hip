@@ -58,10 +58,10 @@ __device__ __forceinline__ double block_min_bcast(double v, double* sh) {
 // Burg simplex prox, functions.py:336-356 (and :264-271 when y != NULL).
 // EPT > 0: gg lives in registers (n <= PB*EPT); EPT == 0: gg is kept in `ggbuf` and re-read.
 template <int EPT>
-__global__ __launch_bounds__(PB) void burg_prox_kernel(const double* __restrict__ y, const double* __restrict__ g,
-                                                      double L, double eps, int64_t n, double* __restrict__ xout,
-                                                      double* __restrict__ ggbuf, int* __restrict__ info,
-                                                      int* __restrict__ flags) {
+__device__ __forceinline__ void burg_prox_body(const double* __restrict__ y, const double* __restrict__ g,
+                                               double L, double eps, int64_t n, double* __restrict__ xout,
+                                               double* __restrict__ ggbuf, int* __restrict__ info,
+                                               int* __restrict__ flags) {
     __shared__ double sh[PB / 64];
     const int tid = threadIdx.x;
     constexpr int R = EPT > 0 ? EPT : 1;
@@ -157,17 +157,37 @@ __global__ __launch_bounds__(PB) void burg_prox_kernel(const double* __restrict_
     }
 }
 
+template <int EPT>
+__global__ __launch_bounds__(PB) void burg_prox_kernel(const double* __restrict__ y, const double* __restrict__ g,
+                                                      double L, double eps, int64_t n, double* __restrict__ xout,
+                                                      double* __restrict__ ggbuf, int* __restrict__ info,
+                                                      int* __restrict__ flags) {
+    burg_prox_body<EPT>(y, g, L, eps, n, xout, ggbuf, info, flags);
+}
+// the prox of every active instance of a batch in one launch: a workgroup per instance (row `instance` of the K x n
+// arrays), its own constant L, its own status words
+template <int EPT>
+__global__ __launch_bounds__(PB) void burg_prox_batch_kernel(BatchAct act, const double* __restrict__ ybase,
+                                                            const double* __restrict__ gbase, int64_t ld, BatchVals Ls,
+                                                            double eps, int64_t n, double* __restrict__ obase,
+                                                            double* __restrict__ ggbase, int* __restrict__ flags) {
+    const int inst = act.idx[blockIdx.x];
+    burg_prox_body<EPT>(ybase ? ybase + (int64_t)inst * ld : nullptr, gbase + (int64_t)inst * ld, Ls.v[inst], eps, n,
+                        obase + (int64_t)inst * ld, ggbase ? ggbase + (int64_t)inst * n : nullptr, flags + 8 * inst + 4,
+                        flags + 8 * inst);
+}
+
 // Streaming reduction, stage 1.  Up to four sums / minima per pass:
 //   q0 = sum g*(x-y)                                  (np.dot(g, x1-x), algorithms.py:53)
 //   q1 = sum x/y - log(x/y) - 1                       (functions.py:253)
 //   q2 = sum z/z1 - log(z/z1) - 1
 //   q3 = min over every vector that enters a divergence (positivity assert, functions.py:252)
-__global__ __launch_bounds__(RB) void ls_terms_partial_kernel(const double* __restrict__ g,
-                                                             const double* __restrict__ x,
-                                                             const double* __restrict__ y,
-                                                             const double* __restrict__ z,
-                                                             const double* __restrict__ z1, int64_t n,
-                                                             int want_div_xy, double* __restrict__ part) {
+__device__ __forceinline__ void ls_terms_partial_body(const double* __restrict__ g,
+                                                      const double* __restrict__ x,
+                                                      const double* __restrict__ y,
+                                                      const double* __restrict__ z,
+                                                      const double* __restrict__ z1, int64_t n,
+                                                      int want_div_xy, double* __restrict__ part) {
     __shared__ double sh[4][RB / 64];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, mn = __builtin_inf();
     const int64_t stride = (int64_t)gridDim.x * RB;
@@ -203,9 +223,29 @@ __global__ __launch_bounds__(RB) void ls_terms_partial_kernel(const double* __re
     }
 }
 
+__global__ __launch_bounds__(RB) void ls_terms_partial_kernel(const double* __restrict__ g,
+                                                             const double* __restrict__ x,
+                                                             const double* __restrict__ y,
+                                                             const double* __restrict__ z,
+                                                             const double* __restrict__ z1, int64_t n,
+                                                             int want_div_xy, double* __restrict__ part) {
+    ls_terms_partial_body(g, x, y, z, z1, n, want_div_xy, part);
+}
+// the same pass for every active instance of a batch (blockIdx.y); partials of instance i at part + i * pstride
+__global__ __launch_bounds__(RB) void ls_terms_partial_batch_kernel(BatchAct act, const double* __restrict__ g,
+                                                                   const double* __restrict__ x,
+                                                                   const double* __restrict__ y,
+                                                                   const double* __restrict__ z,
+                                                                   const double* __restrict__ z1, int64_t ld, int64_t n,
+                                                                   double* __restrict__ part, int64_t pstride) {
+    const int64_t o = (int64_t)act.idx[blockIdx.y] * ld;
+    ls_terms_partial_body(g ? g + o : nullptr, x + o, y + o, z ? z + o : nullptr, z1 ? z1 + o : nullptr, n, 1,
+                          part + (int64_t)act.idx[blockIdx.y] * pstride);
+}
+
 // stage 2: one workgroup adds the partials in block order
-__global__ __launch_bounds__(RB) void ls_terms_final_kernel(const double* __restrict__ part, int nblk,
-                                                           double* __restrict__ out) {
+__device__ __forceinline__ void ls_terms_final_body(const double* __restrict__ part, int nblk,
+                                                    double* __restrict__ out) {
     __shared__ double sh[4][RB / 64];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, mn = __builtin_inf();
     for (int b = threadIdx.x; b < nblk; b += RB) {
@@ -220,6 +260,31 @@ __global__ __launch_bounds__(RB) void ls_terms_final_kernel(const double* __rest
         double a = 0.0, b = 0.0, c = 0.0, d = sh[3][0];
         for (int i = 0; i < RB / 64; ++i) { a += sh[0][i]; b += sh[1][i]; c += sh[2][i]; d = min_nan(d, sh[3][i]); }
         out[0] = a; out[1] = b; out[2] = c; out[3] = d;
+    }
+}
+
+__global__ __launch_bounds__(RB) void ls_terms_final_kernel(const double* __restrict__ part, int nblk,
+                                                           double* __restrict__ out) {
+    ls_terms_final_body(part, nblk, out);
+}
+__global__ __launch_bounds__(RB) void ls_terms_final_batch_kernel(BatchAct act, const double* __restrict__ part,
+                                                                 int64_t pstride, int nblk, double* __restrict__ out) {
+    const int inst = act.idx[blockIdx.x];
+    ls_terms_final_body(part + (int64_t)inst * pstride, nblk, out + 4 * inst);
+}
+
+// out = a*x + b*z for every active instance of a batch (its own a and b), NumPy's rounding as in axpby_kernel
+__global__ __launch_bounds__(RB) void axpby_batch_kernel(BatchAct act, BatchVals a, const double* __restrict__ x, BatchVals b,
+                                                        const double* __restrict__ z, int64_t ld, int64_t n,
+                                                        double* __restrict__ out) {
+    const int inst = act.idx[blockIdx.y];
+    const double ai = a.v[inst], bi = b.v[inst];
+    const int64_t o = (int64_t)inst * ld;
+    const int64_t stride = (int64_t)gridDim.x * RB;
+    for (int64_t i = (int64_t)blockIdx.x * RB + threadIdx.x; i < n; i += stride) {
+        const double p = ai * x[o + i];
+        const double q = bi * z[o + i];
+        out[o + i] = p + q;
     }
 }
 
@@ -629,5 +694,113 @@ extern "C" int accbpg_burg_reg_div_prox(int kind, const double* y_dev, const dou
         set_last_error(kind == 1 ? "Not getting positive solution." : "BurgEntropy prox_map only takes positive value.");
         return ACCBPG_ERR_ASSERT;
     }
+    return ACCBPG_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Length-n kernels over the active instances of a batch (accbpg_dopt_batch_*): K x n arrays, row i = instance i.
+// ------------------------------------------------------------------------------------------------------------
+static int batch_vec_scratch(accbpg_dopt_batch* b) {
+    if (b->vflags) return ACCBPG_OK;
+    const int64_t n = b->inst[0]->n;
+    ACC_HIP(hipMalloc(&b->vflags, sizeof(int) * 8 * (size_t)b->K));
+    ACC_HIP(hipMemset(b->vflags, 0, sizeof(int) * 8 * (size_t)b->K));
+    ACC_HIP(hipMalloc(&b->vout, sizeof(double) * 4 * (size_t)b->K));
+    ACC_HIP(hipMalloc(&b->vpart, sizeof(double) * 4 * RMAXBLK * (size_t)b->K));
+    if (n > (int64_t)PB * 32) ACC_HIP(hipMalloc(&b->vgg, sizeof(double) * (size_t)n * (size_t)b->K));
+    ACC_HIP(hipHostMalloc(&b->vpin, sizeof(double) * 8 * (size_t)b->K, hipHostMallocDefault));
+    return ACCBPG_OK;
+}
+
+static BatchAct batch_active(const accbpg_dopt_batch* b, const int* active_host) {
+    BatchAct act;
+    for (int i = 0; i < b->K && i < BATCH_MAX; ++i)
+        if (!active_host || active_host[i]) act.idx[act.n++] = i;
+    return act;
+}
+
+/* x_out[i] <- BurgEntropySimplex.div_prox_map(y[i], g[i], L_host[i]) for the active instances (y_dev NULL: prox_map).
+ * status_host[i]: ACCBPG_OK or ACCBPG_ERR_ASSERT (L <= 0, or min(y) <= 0).  info_host (optional, 2 ints per instance)
+ * receives {bisection steps, Newton steps}. */
+extern "C" int accbpg_dopt_batch_burg_simplex_div_prox(accbpg_dopt_batch* b, const double* y_dev, const double* g_dev,
+                                                       int64_t ld, const double* L_host, double eps, double* x_out_dev,
+                                                       const int* active_host, int* status_host, int* info_host) {
+    if (!b || !g_dev || !x_out_dev || !L_host || !status_host || b->K > BATCH_MAX) return ACCBPG_ERR_ARG;
+    const int64_t n = b->inst[0]->n;
+    if (ld < n) return ACCBPG_ERR_ARG;
+    ACC_TRY(batch_vec_scratch(b));
+    BatchAct all = batch_active(b, active_host), act;
+    BatchVals Ls;
+    for (int a = 0; a < all.n; ++a) {                           // functions.py:270 / :340: L > 0 is checked before anything runs
+        const int i = all.idx[a];
+        Ls.v[i] = L_host[i];
+        if (!(L_host[i] > 0.0)) status_host[i] = ACCBPG_ERR_ASSERT;
+        else { status_host[i] = ACCBPG_OK; act.idx[act.n++] = i; }
+    }
+    if (act.n == 0) return ACCBPG_OK;
+    hipStream_t s = b->stream;
+    if (n <= (int64_t)PB * 2)
+        burg_prox_batch_kernel<2><<<act.n, PB, 0, s>>>(act, y_dev, g_dev, ld, Ls, eps, n, x_out_dev, nullptr, b->vflags);
+    else if (n <= (int64_t)PB * 8)
+        burg_prox_batch_kernel<8><<<act.n, PB, 0, s>>>(act, y_dev, g_dev, ld, Ls, eps, n, x_out_dev, nullptr, b->vflags);
+    else if (n <= (int64_t)PB * 32)
+        burg_prox_batch_kernel<32><<<act.n, PB, 0, s>>>(act, y_dev, g_dev, ld, Ls, eps, n, x_out_dev, nullptr, b->vflags);
+    else
+        burg_prox_batch_kernel<0><<<act.n, PB, 0, s>>>(act, y_dev, g_dev, ld, Ls, eps, n, x_out_dev, b->vgg, b->vflags);
+    ACC_HIP(hipGetLastError());
+    int* pin_i = reinterpret_cast<int*>(b->vpin);
+    ACC_HIP(hipMemcpyAsync(pin_i, b->vflags, sizeof(int) * 8 * (size_t)b->K, hipMemcpyDeviceToHost, s));
+    ACC_HIP(hipStreamSynchronize(s));
+    for (int a = 0; a < act.n; ++a) {
+        const int i = act.idx[a];
+        if (pin_i[8 * i + FLAG_NONPOS]) status_host[i] = ACCBPG_ERR_ASSERT;     // y.min() > 0, functions.py:270
+        if (info_host) { info_host[2 * i] = pin_i[8 * i + 4]; info_host[2 * i + 1] = pin_i[8 * i + 5]; }
+    }
+    return ACCBPG_OK;
+}
+
+/* out_host[3 i ..] <- { <g_i, x_i - y_i>, D_h(x_i, y_i), D_h(z_i, z1_i) } for the active instances (g, and z with z1,
+ * may be NULL); status_host[i] = ACCBPG_ERR_ASSERT where an entry that enters a divergence is not positive. */
+extern "C" int accbpg_dopt_batch_ls_terms(accbpg_dopt_batch* b, const double* g_dev, const double* x_dev, const double* y_dev,
+                                          const double* z_dev, const double* z1_dev, int64_t ld, const int* active_host,
+                                          double* out_host, int* status_host) {
+    if (!b || !x_dev || !y_dev || !out_host || !status_host || b->K > BATCH_MAX) return ACCBPG_ERR_ARG;
+    if ((z_dev == nullptr) != (z1_dev == nullptr)) return ACCBPG_ERR_ARG;
+    const int64_t n = b->inst[0]->n;
+    if (ld < n) return ACCBPG_ERR_ARG;
+    ACC_TRY(batch_vec_scratch(b));
+    const BatchAct act = batch_active(b, active_host);
+    if (act.n == 0) return ACCBPG_OK;
+    hipStream_t s = b->stream;
+    const int nb = red_blocks(n);
+    ls_terms_partial_batch_kernel<<<dim3(nb, act.n), RB, 0, s>>>(act, g_dev, x_dev, y_dev, z_dev, z1_dev, ld, n, b->vpart,
+                                                                4 * RMAXBLK);
+    ls_terms_final_batch_kernel<<<act.n, RB, 0, s>>>(act, b->vpart, 4 * RMAXBLK, nb, b->vout);
+    ACC_HIP(hipGetLastError());
+    ACC_HIP(hipMemcpyAsync(b->vpin, b->vout, sizeof(double) * 4 * (size_t)b->K, hipMemcpyDeviceToHost, s));
+    ACC_HIP(hipStreamSynchronize(s));
+    for (int a = 0; a < act.n; ++a) {
+        const int i = act.idx[a];
+        out_host[3 * i] = b->vpin[4 * i]; out_host[3 * i + 1] = b->vpin[4 * i + 1]; out_host[3 * i + 2] = b->vpin[4 * i + 2];
+        status_host[i] = (b->vpin[4 * i + 3] > 0.0) ? ACCBPG_OK : ACCBPG_ERR_ASSERT;     // functions.py:252
+    }
+    return ACCBPG_OK;
+}
+
+/* out[i] <- a_host[i] * x[i] + b_host[i] * z[i] for the active instances, NumPy's rounding (algorithms.py:147,150). */
+extern "C" int accbpg_dopt_batch_axpby(accbpg_dopt_batch* b, const double* a_host, const double* x_dev, const double* b_host,
+                                       const double* z_dev, int64_t ld, const int* active_host, double* out_dev) {
+    if (!b || !a_host || !b_host || !x_dev || !z_dev || !out_dev || b->K > BATCH_MAX) return ACCBPG_ERR_ARG;
+    const int64_t n = b->inst[0]->n;
+    if (ld < n) return ACCBPG_ERR_ARG;
+    const BatchAct act = batch_active(b, active_host);
+    if (act.n == 0) return ACCBPG_OK;
+    BatchVals av, bv;
+    for (int i = 0; i < b->K; ++i) { av.v[i] = a_host[i]; bv.v[i] = b_host[i]; }
+    int64_t nb = (n + RB - 1) / RB;
+    if (nb > 256) nb = 256;
+    axpby_batch_kernel<<<dim3((unsigned)nb, act.n), RB, 0, b->stream>>>(act, av, x_dev, bv, z_dev, ld, n, out_dev);
+    ACC_HIP(hipGetLastError());
     return ACCBPG_OK;
 }

@@ -95,7 +95,7 @@ class DOptimalObj(RSmoothFunction):
     (borrowed).  ``self.H``, ``self.m``, ``self.n`` stay readable as in the
     reference (callers use ``f.H``)."""
 
-    def __init__(self, H, _shard=False):
+    def __init__(self, H, _shard=False, _borrowed=None):
         self.H = H
         self.m = H.shape[0]
         self.n = H.shape[1]
@@ -103,11 +103,17 @@ class DOptimalObj(RSmoothFunction):
         assert _shard or self.m < self.n, "DOptimalObj: need m < n"
         self._V, _ = to_dev(H)
         lib = _lib.load()
-        h = C.c_void_p()
-        with torch.cuda.device(self._V.device):
-            rc = lib.accbpg_dopt_create(_ptr(self._V), self.m, self.n, self._V.stride(0), _stream(), C.byref(h),
-                                        1 if _shard else 0)
-        _lib.check(rc, "accbpg_dopt_create")
+        if _borrowed is not None:
+            # one instance of a DOptimalBatch: the handle belongs to the batch (kept alive through _owner)
+            h, self._owner = _borrowed
+            self._owned = False
+        else:
+            h = C.c_void_p()
+            with torch.cuda.device(self._V.device):
+                rc = lib.accbpg_dopt_create(_ptr(self._V), self.m, self.n, self._V.stride(0), _stream(), C.byref(h),
+                                            1 if _shard else 0)
+            _lib.check(rc, "accbpg_dopt_create")
+            self._owned = True
         self._h = h
         self._lib = lib
         self.calls = {"value": 0, "grad": 0}
@@ -126,6 +132,8 @@ class DOptimalObj(RSmoothFunction):
     def __del__(self):
         for name in ("_h", "_h2"):
             h = getattr(self, name, None)
+            if name == "_h" and not getattr(self, "_owned", True):
+                continue
             if h:
                 try:
                     self._lib.accbpg_dopt_destroy(h)

@@ -68,6 +68,8 @@ def parse(argv=None):
                          "per evaluation (strong scaling, BASELINE config 5)")
     ap.add_argument("--instances-per-gpu", type=int, default=None,
                     help="independent instances per GPU advanced concurrently (BASELINE config 4: 8 per GPU)")
+    ap.add_argument("--host-threads", action="store_true",
+                    help="with --instances-per-gpu: one host thread + stream per instance instead of the lock-step batch")
     ap.add_argument("--steady-start", type=int, default=100, help="first iteration of the steady-state window")
     ap.add_argument("--steady-iters", type=int, default=200, help="iterations timed in the steady-state window")
     ap.add_argument("--no-steady", action="store_true")
@@ -331,8 +333,21 @@ def main():
         return alg.BPG_steps(ff, hh, 1.0, x0.clone(), length, verbose=False)
 
     batch = None
+    lockstep = None
     objs = [f]
-    if ipg > 1:
+    if ipg > 1 and args.workload == "abpg" and not shard and not args.host_threads:
+        # BASELINE config 4: the instances of this GPU advance in lock-step, one launch per kernel family for all of
+        # them (accbpg_dopt_batch_*); results are bit-identical to solving them one after the other
+        from accbpg_and_fw_amd.batched import ABPG_batch_steps, DOptimalBatch
+        lockstep = DOptimalBatch([f.V_dev] + [make_instance(m, n, 1 + idx, device) for idx in mine[1:]])
+        objs = [lockstep]
+        prof_objs = []
+        gen = ABPG_batch_steps(lockstep, acc.BurgEntropySimplex(), 1.0, x0, 2, horizon)
+
+        def advance(count=1):
+            for _ in range(count):
+                next(gen)
+    elif ipg > 1:
         if shard or args.workload.startswith("fw"):
             raise SystemExit("--instances-per-gpu applies to the BPG family in instances mode")
         from accbpg_and_fw_amd.batched import BatchStepper
@@ -374,6 +389,7 @@ def main():
 
     def calls_now():
         return {k: sum(o.calls[k] for o in objs) for k in ("value", "grad")}
+    ninst_local = ipg if lockstep is not None else len(objs)
 
     def timed(count):
         """(seconds, max over ranks; oracle calls per step and instance) of `count` further steps."""
@@ -384,7 +400,7 @@ def main():
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
         c1 = calls_now()
-        return dt, {k: (c1[k] - c0[k]) / (count * len(objs)) for k in c0}
+        return dt, {k: (c1[k] - c0[k]) / (count * ninst_local) for k in c0}
 
     if shard and args.workload.startswith("fw"):
         raise SystemExit("shard mode covers the BPG family (the FW solvers are not a multi-GPU config)")
@@ -461,6 +477,14 @@ def main():
     # config 4: gather per-instance bookkeeping by instance index (the full results travel the same way through
     # batched.solve_instances, which is what a caller of the package uses; bench.py steps generators instead)
     gathered = None
+    if lockstep is not None:
+        counts = {idx: lockstep.calls["grad"] // ipg for idx in mine}
+        if world > 1:
+            parts = [None] * world
+            dist.all_gather_object(parts, counts)
+            gathered = {k: v for p in parts for k, v in p.items()}
+        else:
+            gathered = counts
     if batch is not None:
         counts = {idx: o.calls["grad"] for idx, o in zip(mine, objs)}
         if world > 1:
@@ -476,8 +500,11 @@ def main():
         value = ninst * args.steps / elapsed
         if shard:
             layout = "ONE instance, design points sharded over the GPUs, one RCCL all-reduce of the Gram matrix per evaluation"
+        elif lockstep is not None:
+            layout = ("%d independent instances per GPU advancing in lock-step (one launch per kernel family for all of "
+                      "them%s), dealt round-robin over the ranks" % (ipg, "" if lockstep.fused else "; NOT fused at this shape"))
         elif ipg > 1:
-            layout = "%d independent instances per GPU advanced concurrently, dealt round-robin over the ranks" % ipg
+            layout = "%d independent instances per GPU advanced concurrently from host threads, dealt round-robin over the ranks" % ipg
         else:
             layout = "one independent instance per GPU"
         out = {

@@ -99,6 +99,46 @@ int accbpg_dopt_gram_lincomb(accbpg_dopt* h, double a, const double* G1_dev, dou
                              const double* G2_dev, double* out_dev);
 int accbpg_dopt_eval_gram(accbpg_dopt* h, const double* gram_dev, int flag, double* f_host, double* g_dev);
 
+/* ---- Batches of same-shaped instances on one GPU (BASELINE config 4; SURVEY.md 8(b) "*_batched", 8(e).1) ----------
+ * K independent D-optimal problems of one shape advance in lock-step: every entry point below covers the ACTIVE
+ * instances (active_host[i] != 0; NULL = all) with ONE launch per kernel family and ONE readback, and reports a status
+ * per instance.  Vectors are K x n arrays, row i = instance i, leading dimension ld.  The arithmetic of an instance is
+ * that of accbpg_dopt_func_grad / accbpg_burg_simplex_div_prox / accbpg_ls_terms / accbpg_vec_axpby on the handle
+ * accbpg_dopt_batch_instance(b, i) -- bit for bit -- so a batch and a loop over its instances give identical results.
+ * The per-instance decisions (stopping, line search) stay with the caller, who re-issues the instances that need
+ * another pass.  Shapes outside the fused path (m not a multiple of 256, n not a multiple of 128, unaligned rows, more
+ * than 32 instances) are evaluated instance by instance behind the same interface. */
+typedef struct accbpg_dopt_batch accbpg_dopt_batch;
+
+/* V_dev_host: HOST array of K device pointers (m x n row-major matrices, leading dimension ldv, borrowed). */
+int accbpg_dopt_batch_create(const double* const* V_dev_host, int K, int64_t m, int64_t n, int64_t ldv, void* stream,
+                             accbpg_dopt_batch** out);
+int accbpg_dopt_batch_destroy(accbpg_dopt_batch* b);
+int accbpg_dopt_batch_set_stream(accbpg_dopt_batch* b, void* stream);
+int accbpg_dopt_batch_size(accbpg_dopt_batch* b);
+int accbpg_dopt_batch_is_fused(accbpg_dopt_batch* b);          /* 1: one launch per kernel family covers the batch */
+accbpg_dopt* accbpg_dopt_batch_instance(accbpg_dopt_batch* b, int i);   /* owned by the batch */
+
+/* DOptimalObj.func_grad (accbpg/functions.py:43-59) for the active instances.  f_host[i], status_host[i]
+ * (ACCBPG_OK / ACCBPG_ERR_ASSERT: min(x_i) < 0 / ACCBPG_ERR_NOT_PD) are written for those only. */
+int accbpg_dopt_batch_func_grad(accbpg_dopt_batch* b, const double* x_dev, int64_t ldx, const int* active_host, int flag,
+                                double* f_host, double* g_dev, int64_t ldg, int* status_host);
+
+/* BurgEntropySimplex.div_prox_map(y_i, g_i, L_host[i]) (accbpg/functions.py:264-271, 336-356; y_dev NULL: prox_map).
+ * info_host (optional): {bisection steps, Newton steps} per instance. */
+int accbpg_dopt_batch_burg_simplex_div_prox(accbpg_dopt_batch* b, const double* y_dev, const double* g_dev, int64_t ld,
+                                            const double* L_host, double eps, double* x_out_dev, const int* active_host,
+                                            int* status_host, int* info_host);
+
+/* out_host[3i..3i+2] = { <g_i, x_i - y_i>, D_h(x_i, y_i), D_h(z_i, z1_i) } (accbpg/algorithms.py:153-154, 377-378, 387). */
+int accbpg_dopt_batch_ls_terms(accbpg_dopt_batch* b, const double* g_dev, const double* x_dev, const double* y_dev,
+                               const double* z_dev, const double* z1_dev, int64_t ld, const int* active_host,
+                               double* out_host, int* status_host);
+
+/* out_i = a_host[i] * x_i + b_host[i] * z_i (accbpg/algorithms.py:147,150). */
+int accbpg_dopt_batch_axpby(accbpg_dopt_batch* b, const double* a_host, const double* x_dev, const double* b_host,
+                            const double* z_dev, int64_t ld, const int* active_host, double* out_dev);
+
 /* ---- Burg entropy on the simplex: replaces BurgEntropy / BurgEntropySimplex ------------
  * (accbpg/functions.py:238-271, 326-356).  `ws_dev` is caller-provided scratch of at least
  * accbpg_vec_workspace_doubles(n) doubles. */
