@@ -50,6 +50,8 @@ _SIGS = {
     "accbpg_dopt_batch_instance": (_P, [_P, C.c_int]),
     "accbpg_dopt_batch_func_grad": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), _P,
                                               C.c_int64, C.POINTER(C.c_int)]),
+    "accbpg_dopt_batch_func_grad_begin": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int), C.c_int, _P, C.c_int64]),
+    "accbpg_dopt_batch_func_grad_end": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "accbpg_dopt_batch_burg_simplex_div_prox": (C.c_int, [_P, _P, _P, C.c_int64, C.POINTER(C.c_double), C.c_double, _P,
                                                           C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "accbpg_dopt_batch_ls_terms": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_double),

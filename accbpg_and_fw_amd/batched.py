@@ -99,6 +99,34 @@ class DOptimalBatch:
             return fv
         return G if flag == 1 else (fv, G)
 
+    # ---- value evaluations beside the gradient evaluations: a second batch over the same matrices, own stream ----
+    def value_async(self, X, active=None):
+        """Start f(X[i]) for the active instances on a side stream (a twin batch over the same matrices) and
+        return a ticket for ``value_wait``.  Same kernels, same plans: the values are those of ``func_grad(X, 0)``."""
+        twin = getattr(self, "_twin", None)
+        if twin is None:
+            twin = self._twin = DOptimalBatch(self._Vs)
+            with torch.cuda.device(self.device):
+                self._side = torch.cuda.Stream(device=self.device)
+        mask, idx = self._mask(active)
+        with torch.cuda.device(self.device):
+            self._side.wait_stream(torch.cuda.current_stream())          # X is produced on the caller's stream
+            self._lib.accbpg_dopt_batch_set_stream(twin._h, C.c_void_p(self._side.cuda_stream))
+            rc = self._lib.accbpg_dopt_batch_func_grad_begin(twin._h, _ptr(X), X.stride(0), mask, 0, None, self.n)
+        _lib.check(rc, "accbpg_dopt_batch_func_grad_begin")
+        return (X, idx)                                                   # the ticket keeps X alive
+
+    def value_wait(self, ticket):
+        _, idx = ticket
+        f = (C.c_double * self.K)(*([float("nan")] * self.K))
+        st = (C.c_int * self.K)()
+        with torch.cuda.device(self.device):
+            rc = self._lib.accbpg_dopt_batch_func_grad_end(self._twin._h, f, st)
+        _lib.check(rc, "accbpg_dopt_batch_func_grad_end")
+        self._raise(st, idx, "accbpg_dopt_batch_func_grad", "DOptimalObj: x needs to be nonnegative")
+        self.calls["value"] += len(idx)
+        return np.array(f[:], dtype=np.float64)
+
     def prox(self, Y, G, Ls, eps, active=None):
         """Row i: BurgEntropySimplex(eps).div_prox_map(Y[i], G[i], Ls[i]) (Y None: prox_map)."""
         mask, idx = self._mask(active)
@@ -139,12 +167,14 @@ class DOptimalBatch:
         return out
 
 
-def ABPG_batch_steps(batch, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=False, restart=False, restart_rule='g'):
+def ABPG_batch_steps(batch, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=False, restart=False, restart_rule='g',
+                     overlap=True):
     """ABPG (accbpg/algorithms.py:94-180) on the K instances of a ``DOptimalBatch`` in lock-step: every oracle call,
     prox and vector pass covers all instances that are still running.  theta, the restart state and the stopping test
     are kept per instance exactly as the sequential solver keeps them; an instance that stops (D(z+,z) < epsilon)
     drops out of the later launches.  Yields k after every outer iteration; returns, per instance, ABPG's
-    (x, F, G, T) -- bit-identical to ``ABPG(batch.instance(i), h, L, x0, ...)``."""
+    (x, F, G, T) -- bit-identical to ``ABPG(batch.instance(i), h, L, x0, ...)``.  With `overlap` (default) the values
+    F[k] = f(x_i) run on a second stream beside the gradient evaluations at y_i, which do not depend on them."""
     from .algorithms import solve_theta
     K, n = batch.K, batch.n
     t_start = time.time()
@@ -162,12 +192,11 @@ def ABPG_batch_steps(batch, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=Fa
     for k in range(maxitrs):
         if not any(active):
             break
-        fx = batch.func_grad(X, 0, active)                                  # :135
+        ticket = batch.value_async(X, active) if overlap else None          # :135 (beside the gradients below)
+        fx = None if overlap else batch.func_grad(X, 0, active)
         now = time.time() - t_start
         for i in range(K):
             if active[i]:
-                F[i, k] = fx[i] + h.extra_Psi(None)
-                T[i, k] = now
                 if theta_eq and kk[i] > 0:                                  # :142-145
                     theta[i] = solve_theta(theta[i], gamma)
                 else:
@@ -175,6 +204,13 @@ def ABPG_batch_steps(batch, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=Fa
         one_m = [1 - t for t in theta]
         Y = batch.axpby(one_m, X, theta, Z, active)                         # :147
         Gr = batch.func_grad(Y, 1, active)                                  # :148
+        if overlap:
+            fx = batch.value_wait(ticket)
+            now = time.time() - t_start
+        for i in range(K):
+            if active[i]:
+                F[i, k] = fx[i] + h.extra_Psi(None)
+                T[i, k] = now
         Zn = batch.prox(Z, Gr, [t ** (gamma - 1) * L for t in theta], eps_prox, active)    # :149
         Xn = batch.axpby(one_m, X, theta, Zn, active)                       # :150
         terms = batch.ls_terms(None, Xn, Y, Zn, Z, active)                  # :153-154
@@ -209,9 +245,10 @@ def ABPG_batch_steps(batch, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=Fa
     return out
 
 
-def ABPG_batch(batch, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=False, restart=False, restart_rule='g'):
+def ABPG_batch(batch, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=False, restart=False, restart_rule='g',
+               overlap=True):
     """Drain ``ABPG_batch_steps``: list of (x, F, G, T), one per instance."""
-    gen = ABPG_batch_steps(batch, h, L, x0, gamma, maxitrs, epsilon, theta_eq, restart, restart_rule)
+    gen = ABPG_batch_steps(batch, h, L, x0, gamma, maxitrs, epsilon, theta_eq, restart, restart_rule, overlap)
     while True:
         try:
             next(gen)

@@ -131,11 +131,12 @@ static int status_of(const double* st) {
 
 /* func_grad for the instances with active_host[i] != 0 (NULL: all).  x_dev / g_dev: row i = instance i, leading
  * dimensions ldx / ldg.  f_host[i] and status_host[i] (ACCBPG_OK, ACCBPG_ERR_ASSERT for min(x_i) < 0, ACCBPG_ERR_NOT_PD)
- * are written for the active instances only; the return value reports failures of the call itself. */
-extern "C" int accbpg_dopt_batch_func_grad(accbpg_dopt_batch* b, const double* x_dev, int64_t ldx, const int* active_host,
-                                           int flag, double* f_host, double* g_dev, int64_t ldg, int* status_host) {
-    if (!b || !x_dev || flag < 0 || flag > 2 || !status_host || ldx < b->inst[0]->n) return ACCBPG_ERR_ARG;
-    if (flag != 1 && !f_host) return ACCBPG_ERR_ARG;
+ * are written for the active instances only; the return value reports failures of the call itself.
+ * _begin queues the whole evaluation on the batch's stream and returns, _end waits for it: two batches over the same
+ * matrices on different streams let INDEPENDENT evaluations overlap (F[k] = f(x) beside the gradient at y). */
+extern "C" int accbpg_dopt_batch_func_grad_begin(accbpg_dopt_batch* b, const double* x_dev, int64_t ldx,
+                                                 const int* active_host, int flag, double* g_dev, int64_t ldg) {
+    if (!b || !x_dev || flag < 0 || flag > 2 || ldx < b->inst[0]->n) return ACCBPG_ERR_ARG;
     if (flag != 0 && (!g_dev || ldg < b->inst[0]->n)) return ACCBPG_ERR_ARG;
     BatchAct act;
     for (int i = 0; i < b->K; ++i)
@@ -143,6 +144,9 @@ extern "C" int accbpg_dopt_batch_func_grad(accbpg_dopt_batch* b, const double* x
             if (act.n < BATCH_MAX) act.idx[act.n] = i;
             ++act.n;
         }
+    b->pend_act = act; b->pend_x = x_dev; b->pend_ldx = ldx; b->pend_flag = flag; b->pend_g = g_dev; b->pend_ldg = ldg;
+    b->pend_all = (active_host == nullptr);
+    b->pend_fused = false;
     if (act.n == 0) return ACCBPG_OK;
     const bool aligned = ((reinterpret_cast<uintptr_t>(x_dev) & 15) == 0) && ((ldx & 1) == 0);
     if (b->fast && aligned && act.n <= BATCH_MAX) {
@@ -153,6 +157,16 @@ extern "C" int accbpg_dopt_batch_func_grad(accbpg_dopt_batch* b, const double* x
             ACC_TRY(launch_colnorm_batch(b, act, g_dev, ldg, -1.0));
         }
         ACC_HIP(hipMemcpyAsync(b->hpin, b->dscal_all, sizeof(double) * 24 * (size_t)b->K, hipMemcpyDeviceToHost, b->stream));
+        b->pend_fused = true;
+    }
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_dopt_batch_func_grad_end(accbpg_dopt_batch* b, double* f_host, int* status_host) {
+    if (!b || !status_host) return ACCBPG_ERR_ARG;
+    const BatchAct& act = b->pend_act;
+    if (act.n == 0) return ACCBPG_OK;
+    if (b->pend_fused) {
         ACC_HIP(hipStreamSynchronize(b->stream));
         bool aborted = false;
         for (int a = 0; a < act.n; ++a) {
@@ -172,15 +186,24 @@ extern "C" int accbpg_dopt_batch_func_grad(accbpg_dopt_batch* b, const double* x
         b->fast = false;
         for (accbpg_dopt* h : b->inst) h->chol_tiles_off = true;
     }
-    for (int i = 0; i < b->K; ++i) {
-        if (active_host && !active_host[i]) continue;
+    for (int a = 0; a < act.n; ++a) {
+        const int i = act.idx[a];
         accbpg_dopt* h = b->inst[i];
         h->stream = b->stream;
         double fv = 0.0;
-        const int rc = accbpg_dopt_func_grad(h, x_dev + (size_t)i * ldx, flag, &fv, flag != 0 ? g_dev + (size_t)i * ldg : nullptr);
+        const int rc = accbpg_dopt_func_grad(h, b->pend_x + (size_t)i * b->pend_ldx, b->pend_flag, &fv,
+                                             b->pend_flag != 0 ? b->pend_g + (size_t)i * b->pend_ldg : nullptr);
         if (rc == ACCBPG_ERR_HIP || rc == ACCBPG_ERR_ARG) return rc;
         status_host[i] = rc;
         if (f_host) f_host[i] = fv;
     }
     return ACCBPG_OK;
+}
+
+extern "C" int accbpg_dopt_batch_func_grad(accbpg_dopt_batch* b, const double* x_dev, int64_t ldx, const int* active_host,
+                                           int flag, double* f_host, double* g_dev, int64_t ldg, int* status_host) {
+    if (flag != 1 && !f_host) return ACCBPG_ERR_ARG;
+    if (!status_host) return ACCBPG_ERR_ARG;
+    ACC_TRY(accbpg_dopt_batch_func_grad_begin(b, x_dev, ldx, active_host, flag, g_dev, ldg));
+    return accbpg_dopt_batch_func_grad_end(b, f_host, status_host);
 }

@@ -200,6 +200,13 @@ struct accbpg_dopt_batch {
     double* vpart = nullptr;                // K * 4 * 1024 doubles: reduction partials
     double* vgg = nullptr;                  // K * n doubles: gg of the prox when it does not fit in registers
     double* vpin = nullptr;                 // pinned mirror (K * 8 doubles)
+    // the evaluation in flight between _begin and _end
+    accbpg::BatchAct pend_act;
+    const double* pend_x = nullptr;
+    double* pend_g = nullptr;
+    int64_t pend_ldx = 0, pend_ldg = 0;
+    int pend_flag = 0;
+    bool pend_all = false, pend_fused = false;
 };
 struct BatchVals { double v[accbpg::BATCH_MAX]; };          // one scalar per instance, as a kernel argument
 

@@ -123,6 +123,11 @@ accbpg_dopt* accbpg_dopt_batch_instance(accbpg_dopt_batch* b, int i);   /* owned
  * (ACCBPG_OK / ACCBPG_ERR_ASSERT: min(x_i) < 0 / ACCBPG_ERR_NOT_PD) are written for those only. */
 int accbpg_dopt_batch_func_grad(accbpg_dopt_batch* b, const double* x_dev, int64_t ldx, const int* active_host, int flag,
                                 double* f_host, double* g_dev, int64_t ldg, int* status_host);
+/* The same split into enqueue / wait (as accbpg_dopt_func_grad_begin / _end): two batches over the same matrices on
+ * two streams let the value evaluations F[k] = f(x_i) run beside the gradient evaluations at y_i. */
+int accbpg_dopt_batch_func_grad_begin(accbpg_dopt_batch* b, const double* x_dev, int64_t ldx, const int* active_host,
+                                      int flag, double* g_dev, int64_t ldg);
+int accbpg_dopt_batch_func_grad_end(accbpg_dopt_batch* b, double* f_host, int* status_host);
 
 /* BurgEntropySimplex.div_prox_map(y_i, g_i, L_host[i]) (accbpg/functions.py:264-271, 336-356; y_dev NULL: prox_map).
  * info_host (optional): {bisection steps, Newton steps} per instance. */
