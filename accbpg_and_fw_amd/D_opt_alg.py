@@ -41,6 +41,14 @@ class _FWState:
         _lib.check(rc, "accbpg_fw_probe_step")
         return pr
 
+    def flush_logdet(self):
+        """log det(H) of the last ``probe(refresh_logdet=2)`` call (see accbpg_fw_logdet_flush)."""
+        out = C.c_double(0.0)
+        with torch.cuda.device(self.obj.device):
+            rc = self.lib.accbpg_fw_logdet_flush(self.h, C.byref(out))
+        _lib.check(rc, "accbpg_fw_logdet_flush")
+        return out.value
+
     def update(self, p, xscale, xadd, hcoef, hdiv):
         with torch.cuda.device(self.obj.device):
             rc = self.lib.accbpg_fw_update(self.h, int(p), float(xscale), float(xadd), float(hcoef), float(hdiv))
@@ -126,14 +134,32 @@ def D_opt_FW_away(V, x0, eps, maxitrs, verbose=True, verbskip=1, logdet_refresh=
         print("\nSolving D-opt design problem using Frank-Wolfe method with away steps")
         print("     k      F(x)     pos_slack   neg_slack    time")
 
+    # F[k] = log det(H_k) is only logged (no decision reads it), so with the reference's behaviour (a fresh
+    # factorisation every iteration) it is formed on a side stream while this loop already probes, decides and
+    # updates, and lands in F one iteration later -- same kernels, same numbers (accbpg_fw_probe_step, form 2);
+    # a table row is printed when its F value is in.
+    piped = (logdet_refresh == 1)
     logdet_H = -st.logdet_gram
+    owed = None                                                 # iteration whose F (and table row) is still outstanding
+
+    def settle(value):
+        F[owed] = value
+        if verbose and owed % verbskip == 0:
+            print("{0:6d}  {1:10.3e}  {2:10.3e}  {3:10.3e}  {4:6.1f}".format(
+                owed, F[owed], SP[owed], SN[owed], T[owed]))
+
     k = -1
     for k in range(maxitrs):
         refresh = (logdet_refresh > 0) and (k % logdet_refresh == 0)
-        pr = st.probe(away=1, refresh_logdet=1 if refresh else 0)   # :136, :145-147
-        if refresh:
-            logdet_H = pr.logdet_H
-        F[k] = logdet_H
+        pr = st.probe(away=1, refresh_logdet=(2 if piped else 1) if refresh else 0)   # :136, :145-147
+        if piped:
+            if owed is not None:
+                settle(pr.logdet_H)
+            owed = k
+        else:
+            if refresh:
+                logdet_H = pr.logdet_H
+            F[k] = logdet_H
         T[k] = time.time() - start_time
         w_i, w_j = pr.w_i, pr.w_j
         eps_pos = w_i / m - 1                                   # :150
@@ -141,7 +167,7 @@ def D_opt_FW_away(V, x0, eps, maxitrs, verbose=True, verbskip=1, logdet_refresh=
         SP[k] = eps_pos
         SN[k] = eps_neg
 
-        if verbose and k % verbskip == 0:
+        if verbose and not piped and k % verbskip == 0:
             print("{0:6d}  {1:10.3e}  {2:10.3e}  {3:10.3e}  {4:6.1f}".format(
                 k, F[k], eps_pos, eps_neg, T[k]))
 
@@ -161,4 +187,6 @@ def D_opt_FW_away(V, x0, eps, maxitrs, verbose=True, verbskip=1, logdet_refresh=
             st.update(pr.j, 1 + t, -t, coef, 1 + t)
             logdet_H += np.log1p(coef * w_j) - m * np.log1p(t)
 
+    if piped and owed is not None:
+        settle(st.flush_logdet())
     return st.x(), F[0:k + 1], SP[0:k + 1], SN[0:k + 1], T[0:k + 1]

@@ -73,6 +73,7 @@ _SIGS = {
     "accbpg_dopt_get_column": (C.c_int, [_P, C.c_int64, _P]),
     "accbpg_fw_init": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),
     "accbpg_fw_probe_step": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FwProbe)]),
+    "accbpg_fw_logdet_flush": (C.c_int, [_P, C.POINTER(C.c_double)]),
     "accbpg_fw_update": (C.c_int, [_P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double]),
     "accbpg_fw_get_state": (C.c_int, [_P, _P, _P, _P]),
     "accbpg_poisson_create": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _P, _P, C.POINTER(_P)]),

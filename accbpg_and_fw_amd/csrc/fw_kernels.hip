@@ -315,6 +315,8 @@ static int read_scalars(accbpg_dopt* h, int nd, int ni) {
     return ACCBPG_OK;
 }
 
+static int fw_side_collect(accbpg_dopt* h, double* logdet);
+
 extern "C" int accbpg_fw_init(accbpg_dopt* h, const double* x0_dev, double* logdet_gram_host) {
     if (!h || !x0_dev) return ACCBPG_ERR_ARG;
     ACC_TRY(fw_alloc(h));
@@ -349,13 +351,83 @@ extern "C" int accbpg_fw_init(accbpg_dopt* h, const double* x0_dev, double* logd
     ACC_HIP(hipStreamSynchronize(h->stream));
     h->fw_ready = true;
     h->fw_part_nblk = 0;
+    if (h->fw_pipe_pending) {                                   // a factorisation left over from an earlier run
+        double unused;
+        ACC_TRY(fw_side_collect(h, &unused));
+    }
+    h->fw_snap_pending = false;
     return ACCBPG_OK;
+}
+
+// ---- log det(H) one iteration behind (refresh_logdet = 2) ------------------------------------------------------
+// F[k] = log det(H_k) of the away-step variant (D_opt_alg.py:136) is a LOGGED value: no decision of the iteration
+// reads it.  So its O(m^3) factorisation need not sit between two HBM-bound steps: a snapshot of H_k is taken on a
+// side stream and factored there while the main stream probes, decides and applies update k; the value is collected
+// by the next call (or by accbpg_fw_logdet_flush).  Same kernels on the same matrix: the numbers are those of the
+// synchronous form.
+static int fw_side_setup(accbpg_dopt* h) {
+    if (h->fw_side) return ACCBPG_OK;
+    ACC_HIP(hipStreamCreateWithFlags(&h->fw_side, hipStreamNonBlocking));
+    ACC_HIP(hipEventCreateWithFlags(&h->fw_ev_h, hipEventDisableTiming));
+    ACC_HIP(hipEventCreateWithFlags(&h->fw_ev_snap, hipEventDisableTiming));
+    ACC_HIP(hipEventCreateWithFlags(&h->fw_ev_chol, hipEventDisableTiming));
+    ACC_HIP(hipMalloc(&h->fw_sd, sizeof(double) * 24));
+    ACC_HIP(hipMemset(h->fw_sd, 0, sizeof(double) * 24));
+    ACC_HIP(hipHostMalloc(&h->fw_sp, sizeof(double) * 24, hipHostMallocDefault));
+    return ACCBPG_OK;
+}
+
+// factor the snapshot on the side stream with the side scalars (the main stream's probe keeps its own)
+static int fw_side_factor(accbpg_dopt* h, double* snap) {
+    hipStream_t s0 = h->stream;
+    double* d0 = h->dscal;
+    int* f0 = h->dflag;
+    h->stream = h->fw_side; h->dscal = h->fw_sd; h->dflag = reinterpret_cast<int*>(h->fw_sd + 16);
+    const int rc = launch_cholesky(h, h->Lbuf, nullptr, nullptr, snap);
+    h->stream = s0; h->dscal = d0; h->dflag = f0;
+    ACC_TRY(rc);
+    ACC_HIP(hipMemcpyAsync(h->fw_sp, h->fw_sd, sizeof(double) * STATUS_DOUBLES, hipMemcpyDeviceToHost, h->fw_side));
+    ACC_HIP(hipEventRecord(h->fw_ev_chol, h->fw_side));
+    return ACCBPG_OK;
+}
+
+// wait for the side factorisation in flight and return its log det (NaN if the matrix was not positive definite)
+static int fw_side_collect(accbpg_dopt* h, double* logdet) {
+    *logdet = __builtin_nan("");
+    if (!h->fw_pipe_pending) return ACCBPG_OK;
+    ACC_HIP(hipEventSynchronize(h->fw_ev_chol));
+    const int* fl = reinterpret_cast<const int*>(h->fw_sp + 16);
+    if (fl[FLAG_ABORT] && !h->chol_tiles_off) {
+        // the one-launch factorisation gave up a wait: the snapshot is intact, factor it with a launch per block column
+        h->chol_tiles_off = true;
+        ACC_TRY(fw_side_factor(h, h->Gbuf ? h->Gbuf : h->Lbuf));
+        ACC_HIP(hipEventSynchronize(h->fw_ev_chol));
+    }
+    h->fw_pipe_pending = false;
+    if (!fl[FLAG_NOT_PD]) *logdet = h->fw_sp[0];
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_fw_logdet_flush(accbpg_dopt* h, double* logdet_host) {
+    if (!h || !logdet_host) return ACCBPG_ERR_ARG;
+    return fw_side_collect(h, logdet_host);
 }
 
 extern "C" int accbpg_fw_probe_step(accbpg_dopt* h, int away, int refresh_logdet, accbpg_fw_probe* out) {
     if (!h || !out || !h->fw_ready) return ACCBPG_ERR_ARG;
     double logdet = 0.0;
-    if (refresh_logdet) {
+    if (refresh_logdet == 2) {
+        ACC_TRY(fw_side_setup(h));
+        ACC_TRY(fw_side_collect(h, &logdet));                   // the PREVIOUS step's log det(H) (NaN on the first call)
+        double* snap = h->Gbuf ? h->Gbuf : h->Lbuf;
+        ACC_HIP(hipEventRecord(h->fw_ev_h, h->stream));         // H_k is complete behind everything queued so far
+        ACC_HIP(hipStreamWaitEvent(h->fw_side, h->fw_ev_h, 0));
+        ACC_TRY(device_copy(snap, h->fw_H, (size_t)h->m * h->m, h->fw_side));
+        ACC_HIP(hipEventRecord(h->fw_ev_snap, h->fw_side));     // from here on H may change
+        ACC_TRY(fw_side_factor(h, snap));
+        h->fw_pipe_pending = true;
+        h->fw_snap_pending = true;
+    } else if (refresh_logdet) {
         // F[k] = log det(H) from a fresh factorisation of the maintained inverse (D_opt_alg.py:136)
         // (the factor goes to Lbuf; H itself is read in place by the one-launch kernel, copied otherwise)
         ACC_TRY(launch_cholesky(h, h->Lbuf, nullptr, nullptr, h->fw_H));
@@ -402,6 +474,10 @@ extern "C" int accbpg_fw_update(accbpg_dopt* h, int64_t p, double xscale, double
         return ACCBPG_ERR_ARG;
     }
     const int64_t m = h->m, n = h->n;
+    if (h->fw_snap_pending) {                                   // the side stream's snapshot of H comes before this update
+        ACC_HIP(hipStreamWaitEvent(h->stream, h->fw_ev_snap, 0));
+        h->fw_snap_pending = false;
+    }
     double* vp = h->fw_hv + m;
     int64_t gb = (std::max(n, m) + FB - 1) / FB;
     if (gb > 1024) gb = 1024;

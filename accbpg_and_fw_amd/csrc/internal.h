@@ -151,6 +151,13 @@ struct accbpg_dopt {
     // Frank-Wolfe state
     double *fw_x = nullptr, *fw_w = nullptr, *fw_H = nullptr, *fw_hv = nullptr;
     bool fw_ready = false;
+    // log det(H) of the away-step variant factored on a side stream, one iteration behind the step it belongs to
+    hipStream_t fw_side = nullptr;
+    hipEvent_t fw_ev_h = nullptr, fw_ev_snap = nullptr, fw_ev_chol = nullptr;
+    double* fw_sd = nullptr;        // device scalars + flags of the side factorisation (24 doubles)
+    double* fw_sp = nullptr;        // pinned mirror
+    bool fw_pipe_pending = false;   // a side factorisation is in flight
+    bool fw_snap_pending = false;   // ... and its snapshot of H may not have been taken yet
     int fw_part_nblk = 0;       // probe stage-1 records left behind by the last w update (0: none)
     bool fw_part_away = false;  // support threshold they were computed for
 

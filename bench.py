@@ -138,7 +138,7 @@ class FWStepper:
 
     def step(self):
         st, m = self.st, self.m
-        pr = st.probe(away=1 if self.away else 0, refresh_logdet=1 if self.away else 0)
+        pr = st.probe(away=1 if self.away else 0, refresh_logdet=2 if self.away else 0)   # F[k] one iteration behind, as D_opt_FW_away
         w_i, w_j = pr.w_i, pr.w_j
         eps_pos, eps_neg = w_i / m - 1, 1 - w_j / m
         if (not self.away) or eps_pos >= eps_neg:

@@ -225,6 +225,12 @@ int accbpg_fw_init(accbpg_dopt* h, const double* x0_dev, double* logdet_gram_hos
  * (D_opt_alg.py:146-147).  refresh_logdet != 0 also refactors H for logdet_H (D_opt_alg.py:136). */
 int accbpg_fw_probe_step(accbpg_dopt* h, int away, int refresh_logdet, accbpg_fw_probe* probe_host);
 
+/* refresh_logdet = 2 is the pipelined form of 1: log det(H) is a logged value that no decision of the iteration reads
+ * (D_opt_alg.py:136 -> F[k] only), so a snapshot of the current H is factored on a side stream while the caller goes on
+ * to probe, decide and update; probe_host->logdet_H then holds the value that belongs to the PREVIOUS call made this way
+ * (NaN on the first), and accbpg_fw_logdet_flush collects the last one.  Same kernels on the same matrices as form 1. */
+int accbpg_fw_logdet_flush(accbpg_dopt* h, double* logdet_host);
+
 /* One rank-one update with pivot column p (i for a Frank-Wolfe step, j for an away step):
  *   x <- x*xscale; x[p] += xadd; Hv = H V[:,p];
  *   H <- (H + hcoef * Hv Hv^T) * hscale_inv ...  written exactly as
