@@ -177,6 +177,154 @@ __global__ __launch_bounds__(PB) void burg_prox_batch_kernel(BatchAct act, const
                         flags + 8 * inst);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same prox over SEVERAL workgroups for long vectors (n > 32768: BASELINE config 5 has n = 262144, replicated on
+// every rank): each workgroup keeps its slice of gg in registers and runs the scalar loop itself; the two sums of a
+// Newton step (phi and phi' at the same c: the reference evaluates phi at the new c and then phi' at that c) travel in
+// ONE exchange: every workgroup publishes its two partial sums (write-through stores, then an epoch flag), waits for the
+// flags of all others, and adds the partials in workgroup order -- so every workgroup obtains bit-identical totals and
+// takes identical decisions, with no further communication.  Exchange r uses slot set r & 1 (a workgroup can only be
+// one exchange ahead of the slowest).  Every wait is bounded: on a timeout the launch raises flags[4] and the host
+// reruns the single-workgroup kernel.  All workgroups must be resident together (at most 128 of 1024 threads).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) double pm_gdouble;
+typedef __attribute__((address_space(1))) int pm_gint;
+struct ProxMultiShared {
+    double* part;      // [2][G][2] partial sums
+    int* epoch;        // [G] last exchange each workgroup has published (1-based)
+    int* abortw;
+};
+template <int OP>      // 0: sums of both values, 1: minimum of the first
+__device__ __forceinline__ bool pm_exchange(const ProxMultiShared sh, int G, int round, double& a, double& b, double* lds,
+                                            long long limit) {
+    const int w = blockIdx.x;
+    double* slot = sh.part + ((size_t)(round & 1) * G + w) * 2;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store((pm_gdouble*)slot, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((pm_gdouble*)(slot + 1), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store((pm_gint*)(sh.epoch + w), round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int ok = 1;
+    if (threadIdx.x < 64) {
+        // lane l waits for the workgroups l, l + 64, ...
+        const long long t0 = wall_clock64();
+        unsigned spins = 0;
+        for (int v = threadIdx.x; v < G; v += 64) {
+            while (__hip_atomic_load((const pm_gint*)(sh.epoch + v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round + 1) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 31u) == 0u) {
+                    if (__hip_atomic_load((const pm_gint*)sh.abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+                    if (wall_clock64() - t0 > limit) {
+                        __hip_atomic_store((pm_gint*)sh.abortw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                }
+            }
+            if (!ok) break;
+        }
+        ok = __all(ok);
+        if (ok && threadIdx.x == 0) {
+            // one lane adds the partials in workgroup order (every workgroup does the same sum)
+            const double* base = sh.part + (size_t)(round & 1) * G * 2;
+            double sa = __hip_atomic_load((const pm_gdouble*)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double sb = __hip_atomic_load((const pm_gdouble*)(base + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int v = 1; v < G; ++v) {
+                const double pa = __hip_atomic_load((const pm_gdouble*)(base + 2 * v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double pb = __hip_atomic_load((const pm_gdouble*)(base + 2 * v + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (OP == 0) { sa += pa; sb += pb; }
+                else { sa = min_nan(sa, pa); }
+            }
+            lds[0] = sa; lds[1] = sb;
+        }
+        if (threadIdx.x == 0) lds[2] = ok ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    a = lds[0]; b = lds[1];
+    const bool good = lds[2] != 0.0;
+    __syncthreads();
+    return good;
+}
+
+template <int EPT>
+__global__ __launch_bounds__(PB) void burg_prox_multi_kernel(const double* __restrict__ y, const double* __restrict__ g,
+                                                            double L, double eps, int64_t n, double* __restrict__ xout,
+                                                            ProxMultiShared shm, int G, int* __restrict__ info,
+                                                            int* __restrict__ flags, long long limit) {
+    __shared__ double sh[PB / 64];
+    __shared__ double xch[4];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * PB * EPT;
+    double gg[EPT];
+    const double inf = __builtin_inf();
+    double lmin = inf;
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int64_t i = base + tid + (int64_t)PB * e;
+        double v = inf;
+        if (i < n) {
+            double a = g[i];
+            if (y != nullptr) {
+                const double yi = y[i];
+                if (!(yi > 0.0)) bad = true;
+                const double t = -1.0 / yi;       // h.gradient(y)      functions.py:248
+                a = a - L * t;                    // g - L*grad         functions.py:271
+            }
+            v = a / L;                            // gg = g / L         functions.py:341
+        }
+        gg[e] = v;
+        lmin = min_nan(lmin, v);
+    }
+    int round = 0;
+    double m0 = block_min_bcast(lmin, sh), m1 = 0.0;
+    if (!pm_exchange<1>(shm, G, round++, m0, m1, xch, limit)) return;
+    const double cmin = -m0;                                   // functions.py:342
+    // phi(c) = sum 1/(gg+c) - 1 and phi'(c) = sum -1/(gg+c)^2, both at the same c, in one exchange
+    auto both = [&](double c, double& fc, double& fpc) -> bool {
+        double s = 0.0, d = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const double r = gg[e] + c;
+            s += 1.0 / r;
+            d += -1.0 / (r * r);
+        }
+        s = block_sum_bcast(s, sh);
+        d = block_sum_bcast(d, sh);
+        if (!pm_exchange<0>(shm, G, round++, s, d, xch, limit)) return false;
+        fc = s - 1.0;
+        fpc = d;
+        return true;
+    };
+    double c = cmin + 1.0;                                     // functions.py:344
+    int nb = 0, nn = 0;
+    double fc, fpc;
+    if (!both(c, fc, fpc)) return;
+    while (fc < 0.0 && nb < 4096) {                            // functions.py:345-346
+        c = (cmin + c) / 2.0;
+        if (!both(c, fc, fpc)) return;
+        ++nb;
+    }
+    while (fabs(fc) > eps && nn < 4096) {                      // functions.py:349
+        const double step = fc / fpc;                          // :350 (phi' at the current c came with phi)
+        if ((c - (c - step)) == 0.0) break;                    // :351-352
+        c = c - step;                                          // :353
+        if (!both(c, fc, fpc)) return;                         // :354
+        ++nn;
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int64_t i = base + tid + (int64_t)PB * e;
+        if (i < n) xout[i] = 1.0 / (gg[e] + c);                // :355
+    }
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
+    if (tid == 0) {
+        if (any_bad) atomicOr(flags + FLAG_NONPOS, 1);
+        if (blockIdx.x == 0) { info[0] = nb; info[1] = nn; }
+    }
+}
+
 // Streaming reduction, stage 1.  Up to four sums / minima per pass:
 //   q0 = sum g*(x-y)                                  (np.dot(g, x1-x), algorithms.py:53)
 //   q1 = sum x/y - log(x/y) - 1                       (functions.py:253)
@@ -503,6 +651,8 @@ static int ensure_scratch() {
     return ACCBPG_OK;
 }
 
+static bool g_prox_multi_off = false;    // set when the multi-workgroup prox had to give up a wait (then: one workgroup)
+
 int64_t vec_ws_doubles(int64_t n) { return n + 4 * RMAXBLK + 64; }
 
 static int red_blocks(int64_t n) {
@@ -526,6 +676,33 @@ extern "C" int accbpg_burg_simplex_div_prox(const double* y_dev, const double* g
     ACC_TRY(ensure_scratch());
     hipStream_t s = (hipStream_t)stream;
     int* g_info = g_flags + 4;                                  // {bisection, newton} right behind the flags
+    if (n > (int64_t)PB * 32 && n <= (int64_t)PB * 32 * 128 && !g_prox_multi_off) {
+        // long vectors: several workgroups, each with its slice in registers (ws_dev: exchange slots, then the flags)
+        const bool wide = n > (int64_t)PB * 8 * 128;
+        const int ept = wide ? 32 : 8;
+        const int G = (int)((n + (int64_t)PB * ept - 1) / ((int64_t)PB * ept));
+        ProxMultiShared shm;
+        shm.part = ws_dev;
+        shm.epoch = reinterpret_cast<int*>(ws_dev + 4 * G);
+        shm.abortw = shm.epoch + G;
+        ACC_HIP(hipMemsetAsync(ws_dev, 0, sizeof(double) * 4 * G + sizeof(int) * (G + 4), s));
+        ACC_HIP(hipMemsetAsync(g_flags, 0, 8 * sizeof(int), s));
+        if (wide)
+            burg_prox_multi_kernel<32><<<G, PB, 0, s>>>(y_dev, g_dev, L, eps, n, x_out_dev, shm, G, g_info, g_flags, 20000000LL);
+        else
+            burg_prox_multi_kernel<8><<<G, PB, 0, s>>>(y_dev, g_dev, L, eps, n, x_out_dev, shm, G, g_info, g_flags, 20000000LL);
+        ACC_HIP(hipGetLastError());
+        int* pin_m = reinterpret_cast<int*>(g_pin);
+        ACC_HIP(hipMemcpyAsync(pin_m, g_flags, 6 * sizeof(int), hipMemcpyDeviceToHost, s));
+        ACC_HIP(hipMemcpyAsync(pin_m + 8, shm.abortw, sizeof(int), hipMemcpyDeviceToHost, s));
+        ACC_HIP(hipStreamSynchronize(s));
+        if (pin_m[8] == 0) {
+            if (info_host) { info_host[0] = pin_m[4]; info_host[1] = pin_m[5]; }
+            if (pin_m[FLAG_NONPOS]) return ACCBPG_ERR_ASSERT;     // y.min() > 0, functions.py:270
+            return ACCBPG_OK;
+        }
+        g_prox_multi_off = true;                                // a wait timed out: one workgroup from here on
+    }
     if (n <= (int64_t)PB * 2)
         burg_prox_kernel<2><<<1, PB, 0, s>>>(y_dev, g_dev, L, eps, n, x_out_dev, ws_dev, g_info, g_flags);
     else if (n <= (int64_t)PB * 8)
