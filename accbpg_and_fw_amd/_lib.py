@@ -11,7 +11,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libaccbpg_hip.so")
+# (ACCBPG_HIP_LIB: development builds of the same library, e.g. the experiment of DESIGN.md section 4)
+LIB_PATH = os.environ.get("ACCBPG_HIP_LIB") or os.path.join(_HERE, "lib", "libaccbpg_hip.so")
 
 OK, ERR_ASSERT, ERR_NOT_PD, ERR_HIP, ERR_ARG = 0, 1, 2, 3, 4
 

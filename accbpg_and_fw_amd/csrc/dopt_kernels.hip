@@ -1323,8 +1323,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void chol_step_kernel(double* __restri
         if (tid == 0) {
             // consecutive launches add to one scalar from different XCDs: device-scope atomic, not a plain
             // read-modify-write through whichever L2 the workgroup sits behind
+#if defined(ACCBPG_PLAIN_LOGDET) && ACCBPG_PLAIN_LOGDET
+            *logdet += 2.0 * (red[0] + red[1] + red[2] + red[3]);     // (experiment build: see DESIGN.md section 4)
+#else
             __hip_atomic_fetch_add(logdet, 2.0 * (red[0] + red[1] + red[2] + red[3]), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+#endif
             if (bad) flags[FLAG_NOT_PD] = 1;
         }
         if (Winv != nullptr) {
@@ -1885,7 +1889,11 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(const double* __restrict
 // resets the scalars and the status flags; with x != NULL also the x >= 0 check of functions.py:45
 __global__ __launch_bounds__(1024) void zero_scalars_kernel(double* dscal, int* dflag, const double* __restrict__ x,
                                                           int64_t n, int* __restrict__ ready, int nready) {
+#if defined(ACCBPG_PLAIN_LOGDET) && ACCBPG_PLAIN_LOGDET
+    if (threadIdx.x < 8) dscal[threadIdx.x] = 0.0;
+#else
     if (threadIdx.x < 8) __hip_atomic_store(dscal + threadIdx.x, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     if (threadIdx.x < 8) dflag[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < nready; i += blockDim.x) ready[i] = 0;     // hand-off flags of the one-launch Cholesky
     if (x == nullptr) return;

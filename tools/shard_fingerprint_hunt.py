@@ -42,6 +42,11 @@ m, n, parts = 300, 3000, 3
 np.random.seed(11); V = np.random.randn(m, n)
 x0 = np.ones(n) / n; h = acc.BurgEntropySimplex()
 fs = Traced(V, parts)
+if os.environ.get("HUNT_STEP_KERNELS", "1") == "1":
+    # the launch-per-block-column Cholesky (the path the events were seen on), not the one-launch kernel
+    from accbpg_and_fw_amd import _lib
+    for obj in fs.objs:
+        _lib.load().accbpg_debug_chol_variant(obj._h, 64)
 ref = acc.ABPG(fs, h, 1.0, x0, gamma=2, maxitrs=15, verbose=False); reflog = fs.log
 t0 = time.time(); runs = 0; events = 0; tick = t0
 while time.time() - t0 < budget:
