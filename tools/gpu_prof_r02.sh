@@ -47,15 +47,17 @@ run_bench bench_cfg1 --m 80 --n 200 --workload bpg --steps 500 --warmup 50 --no-
 run_bench bench_cfg5_share --m 8192 --n 32768 --workload abpg --steps 5 --warmup 2 --no-cpu-baseline --no-steady --no-variants
 run_bench bench_poisson --workload poisson_abpg --steps 50 --warmup 5
 fi
+if [ "${STAGE:-all}" = "all" ] || [ "$STAGE" = "prof" ] || [ "$STAGE" = "pmc" ]; then
+prof default --steps 20 --warmup 5 --no-variants --no-steady --no-cpu-baseline --no-overlap
+fi
 if [ "${STAGE:-all}" = "all" ] || [ "$STAGE" = "prof" ]; then
-prof default --steps 20 --warmup 5 --no-variants --no-steady --no-cpu-baseline
 prof steady --steps 20 --warmup 5 --no-variants --no-cpu-baseline
 prof fw --config 3 --workload fw --steps 400 --warmup 20 --no-cpu-baseline
 prof fw_away --config 3 --steps 300 --warmup 20 --no-cpu-baseline
 prof cfg4 --config 4 --steps 100 --warmup 10 --no-steady --no-cpu-baseline
 fi
 if [ "${STAGE:-all}" = "all" ] || [ "$STAGE" = "pmc" ]; then
-A="--steps 4 --warmup 2 --no-variants --no-steady --no-cpu-baseline"
+A="--steps 4 --warmup 2 --no-variants --no-steady --no-cpu-baseline --no-overlap"
 pmc fetch FETCH_SIZE -- $A
 pmc write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- $A
 pmc sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- $A
