@@ -315,8 +315,8 @@ def main():
         f = acc.DOptimalObj(make_instance(m, n, 1 + mine[0], device))
         prof_objs = [f]
     overlap = (not args.no_overlap) and (not shard) and hasattr(f, "overlap_values")
-    if overlap:
-        f.overlap_values(True)
+    if hasattr(f, "overlap_values"):
+        f.overlap_values(overlap)
     if args.linear_gram and not shard:
         f.linear_gram(True)
     h = acc.BurgEntropySimplex()
