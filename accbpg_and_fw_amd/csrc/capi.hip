@@ -26,7 +26,7 @@ static int read_status(accbpg_dopt* h) {
 
 using namespace accbpg;
 
-extern "C" int accbpg_abi_version(void) { return 1; }
+extern "C" int accbpg_abi_version(void) { return 2; }   // 2: batches, one-launch Cholesky, pipelined FW log det
 extern "C" const char* accbpg_last_error(void) { return g_err; }
 
 namespace accbpg {
