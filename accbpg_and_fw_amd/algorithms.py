@@ -47,6 +47,13 @@ def _value_begin(f, x, combo):
     return ("value", _value(f, x, combo))
 
 
+def _can_speculate(f, x, checkdiv):
+    """Gradient evaluations may be started ahead of the line-search decision on this package's D-optimal objective
+    (DOptimalObj.speculate, default) when it evaluates directly, on the device, with the side stream in use."""
+    return (not checkdiv) and (not _lin(f)) and getattr(f, "_spec", False) and getattr(f, "_overlap", False) \
+        and not getattr(f, "_prof", False) and hasattr(f, "grad_async") and isinstance(x, torch.Tensor) and x.is_cuda
+
+
 def _value_end(f, pending):
     kind, payload = pending
     return f.value_wait(payload) if kind == "ticket" else payload
@@ -252,6 +259,7 @@ def ABPG_gain_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, G0=1,
     kk = 0
     Gdr = 0.0
     xcombo = None
+    retries_before = 0      # failed trials of the previous iteration: how far ahead the next one starts gradients
     k = -1
     for k in range(maxitrs):
         pending = _value_begin(f, x, xcombo)                    # :347 (runs beside the first gradient below)
@@ -261,20 +269,30 @@ def ABPG_gain_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, G0=1,
         G_prev, theta_prev = G, theta
         G = G / ls_dec                                          # :358
 
+        def theta_for(Gt):                                      # :362-367 for a trial gain Gt
+            if kk == 0:
+                return theta
+            if theta_eq:
+                return solve_theta(theta_prev, gamma, Gt / G_prev)
+            alpha = Gt / G_prev
+            return theta_prev * ((1 + alpha * (gamma - 1)) / (gamma * alpha + theta_prev))
+
+        ahead = _can_speculate(f, x_prev, checkdiv)
+        started = None                                          # (y, ticket) of a gradient evaluation started ahead
+        failed = 0
         searching = True
         while searching:                                        # :361
-            if kk > 0:
-                if theta_eq:
-                    theta = solve_theta(theta_prev, gamma, G / G_prev)
-                else:
-                    alpha = G / G_prev
-                    theta = theta_prev * ((1 + alpha * (gamma - 1)) / (gamma * alpha + theta_prev))
-
-            y = vec_axpby(1 - theta, x_prev, theta, z_prev)     # :369
-            if _lin(f):
-                fy, g = f.func_grad_combo(y, (1 - theta, x_prev, theta, z_prev), 2)
+            theta = theta_for(G)
+            if started is not None:
+                y, ticket = started                             # the point and the evaluation of this very trial
+                started = None
+                fy, g = f.grad_wait(ticket)
             else:
-                fy, g = f.func_grad(y)                          # :371
+                y = vec_axpby(1 - theta, x_prev, theta, z_prev)  # :369
+                if _lin(f):
+                    fy, g = f.func_grad_combo(y, (1 - theta, x_prev, theta, z_prev), 2)
+                else:
+                    fy, g = f.func_grad(y)                      # :371
             if pending is not None:
                 F[k] = _value_end(f, pending) + h.extra_Psi(x_prev)   # :348
                 T[k] = _stamp(f, pending, t_start, t_known)           # :349
@@ -294,10 +312,21 @@ def ABPG_gain_steps(f, h, L, x0, gamma, maxitrs, epsilon=1e-14, G0=1,
             if checkdiv:
                 searching = (Gdr > G)                           # :385
             else:
+                if ahead and failed < retries_before:
+                    # the previous iteration failed this trial too: the next trial's gradient (a function of host
+                    # scalars and of x_1, z_1 only) goes out on the side stream beside the value test below
+                    theta_next = theta_for(G * ls_inc)
+                    y_next = vec_axpby(1 - theta_next, x_prev, theta_next, z_prev)
+                    started = (y_next, f.grad_async(y_next))
                 searching = (_value(f, x, xcombo) > fy + lin + theta ** gamma * G * L * dzz)   # :387
 
             if searching:
                 G = G * ls_inc                                  # :390
+                failed += 1
+            elif started is not None:
+                f.grad_drop(started[1])                         # the trial passed: not needed
+                started = None
+        retries_before = failed
 
         Gain[k] = G
         Gdiv[k] = Gdr

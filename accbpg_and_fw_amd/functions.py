@@ -119,6 +119,8 @@ class DOptimalObj(RSmoothFunction):
         self.calls = {"value": 0, "grad": 0}
         # F[k] = f(x) of the accelerated solvers runs beside the gradient evaluation (see overlap_values())
         self._overlap = True
+        self._spec = False
+        self.spec_unused = 0
         self._prof = False
         # opt-in reuse of resident Gram matrices through linearity (see linear_gram())
         self._lin = False
@@ -156,16 +158,7 @@ class DOptimalObj(RSmoothFunction):
         latency-bound factorisation of one evaluation runs under the MFMA-bound products of the
         other.  Same kernels, same results as ``f(x)``."""
         assert x.numel() == self.n, "DOptimalObj: x.size not equal to n"
-        if getattr(self, "_h2", None) is None:
-            h2 = C.c_void_p()
-            with torch.cuda.device(self._V.device):
-                self._side = torch.cuda.Stream(device=self._V.device)
-                rc = self._lib.accbpg_dopt_create(_ptr(self._V), self.m, self.n, self._V.stride(0),
-                                                  C.c_void_p(self._side.cuda_stream), C.byref(h2), 1)
-            _lib.check(rc, "accbpg_dopt_create")
-            self._h2 = h2
-            if self._prof:
-                self._lib.accbpg_dopt_profile_enable(self._h2, 1)
+        self._side_handle()
         with torch.cuda.device(self._V.device):
             self._side.wait_stream(torch.cuda.current_stream())          # x is produced on the caller's stream
             rc = self._lib.accbpg_dopt_func_grad_begin(self._h2, _ptr(x), 0, None)
@@ -179,6 +172,60 @@ class DOptimalObj(RSmoothFunction):
         _lib.check(rc, "accbpg_dopt_func_grad_end", "DOptimalObj: x needs to be nonnegative")
         self.calls["value"] += 1
         return fval.value
+
+    # ---- a gradient evaluation started ahead of the decision that may need it (second handle, second stream) ----
+    def speculate(self, enable=True):
+        """Opt-in.  ABPG_gain's gain is cut before every search (accbpg/algorithms.py:358) and raised again on
+        failure (:390), so once it has settled the search retries about once per iteration.  With this switch on the
+        solver starts the gradient evaluation of the NEXT trial point -- which depends on host scalars and the
+        previous iterates only -- on the side stream beside the value test of the current one, whenever the previous
+        iteration needed that retry too; a trial that passes leaves the extra evaluation unused.  Every evaluation
+        that IS used is the one the sequential loop would have made: results are bit-identical
+        (test_gradients_started_ahead_change_nothing).  Off by default: the retry counts are irregular (0,1,1,2,...
+        around an average of one), about a quarter of the evaluations started ahead go unused, and an unused one
+        costs more than a used one saves -- measured 50.5 -> 47.7 it/s at (2048,32768), 562 -> 578 at (512,8192)."""
+        self._spec = bool(enable)
+        return self
+
+    def _side_handle(self):
+        if getattr(self, "_h2", None) is None:
+            h2 = C.c_void_p()
+            with torch.cuda.device(self._V.device):
+                self._side = torch.cuda.Stream(device=self._V.device)
+                rc = self._lib.accbpg_dopt_create(_ptr(self._V), self.m, self.n, self._V.stride(0),
+                                                  C.c_void_p(self._side.cuda_stream), C.byref(h2), 1)
+            _lib.check(rc, "accbpg_dopt_create")
+            self._h2 = h2
+            if self._prof:
+                self._lib.accbpg_dopt_profile_enable(self._h2, 1)
+        return self._h2
+
+    def grad_async(self, y):
+        """Start func_grad(y, 2) on the side stream; returns a ticket for ``grad_wait`` / ``grad_drop``."""
+        h2 = self._side_handle()
+        g = torch.empty(self.n, dtype=torch.float64, device=self._V.device)
+        with torch.cuda.device(self._V.device):
+            self._side.wait_stream(torch.cuda.current_stream())          # y is produced on the caller's stream
+            y.record_stream(self._side)
+            g.record_stream(self._side)
+            rc = self._lib.accbpg_dopt_func_grad_begin(h2, _ptr(y), 2, _ptr(g))
+        _lib.check(rc, "accbpg_dopt_func_grad_begin")
+        return (y, g)
+
+    def grad_wait(self, ticket):
+        y, g = ticket
+        fval = C.c_double(0.0)
+        with torch.cuda.device(self._V.device):
+            rc = self._lib.accbpg_dopt_func_grad_end(self._h2, C.byref(fval))
+            torch.cuda.current_stream().wait_stream(self._side)          # g is consumed on the caller's stream
+        _lib.check(rc, "accbpg_dopt_func_grad_end", "DOptimalObj: x needs to be nonnegative")
+        self.calls["grad"] += 1
+        return fval.value, g
+
+    def grad_drop(self, ticket):
+        """The trial passed: the evaluation started ahead is not needed (it finishes on its own; its buffers are
+        returned to the allocator only behind it)."""
+        self.spec_unused += 1
 
     def value_lead_seconds(self):
         """How long before the last evaluation on the solver's stream the last side-stream value was known

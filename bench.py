@@ -75,6 +75,9 @@ def parse(argv=None):
     ap.add_argument("--no-steady", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="evaluate F[k] = f(x) on the solver's own stream instead of beside the gradient evaluation")
+    ap.add_argument("--speculation", action="store_true",
+                    help="ABPG_gain: start the next trial's gradient evaluation beside the current value test "
+                         "(DOptimalObj.speculate; off by default, see its docstring)")
     ap.add_argument("--linear-gram", action="store_true",
                     help="measure with Gram-matrix reuse through linearity switched on (extension); the "
                          "default run reports it separately as linear_gram_variant")
@@ -317,6 +320,8 @@ def main():
     overlap = (not args.no_overlap) and (not shard) and hasattr(f, "overlap_values")
     if hasattr(f, "overlap_values"):
         f.overlap_values(overlap)
+    if hasattr(f, "speculate"):
+        f.speculate(args.speculation)
     if args.linear_gram and not shard:
         f.linear_gram(True)
     h = acc.BurgEntropySimplex()
@@ -424,10 +429,13 @@ def main():
         if done < args.steady_start:
             advance(args.steady_start - done)
             done = args.steady_start
+        spec0 = getattr(f, "spec_unused", 0)
         sdt, scalls = timed(args.steady_iters)
         steady_out = {"value": (1 if shard else world * ipg) * args.steady_iters / sdt, "unit": "iterations/s",
                       "ms_per_step": 1e3 * sdt / args.steady_iters, "first_iteration": done,
                       "iterations": args.steady_iters, "oracle_calls_per_step": scalls,
+                      "gradients_started_ahead_unused_per_step":
+                          (getattr(f, "spec_unused", 0) - spec0) / args.steady_iters if hasattr(f, "spec_unused") else None,
                       "note": "same run continued; for ABPG_gain the gain is cut by ls_dec before every search, so "
                               "after the first ~20-30 iterations every iteration retries about once "
                               "(accbpg/algorithms.py:358-390)"}

@@ -914,6 +914,32 @@ def test_overlapped_value_evaluation_is_identical(acc, shape):
         f.value_wait(f.value_async(bad))
 
 
+@pytest.mark.parametrize("shape,opts", [((300, 3000), dict(gamma=2)), ((512, 8192), dict(gamma=2, G0=0.1)),
+                                        ((256, 4096), dict(gamma=2, ls_inc=1.5, ls_dec=1.1, theta_eq=False, restart=True)),
+                                        ((128, 1024), dict(gamma=1.5, G0=0.1, restart=True, restart_rule='f'))])
+def test_gradients_started_ahead_change_nothing(acc, shape, opts):
+    """ABPG_gain starts the next trial's gradient evaluation beside the current value test when the previous
+    iteration needed that retry (DOptimalObj.speculate, default).  Every evaluation that is used is the one the
+    sequential loop makes: the whole run is bit-identical to the run without it, the oracle-call counts are the
+    same, and once the search has settled into its retry pattern few started evaluations go unused."""
+    f, h, L, x0 = acc.D_opt_design(shape[0], shape[1], randseed=8)
+    iters = 150
+    f.speculate(False)
+    c0 = dict(f.calls)
+    a = acc.ABPG_gain(f, h, L, x0, maxitrs=iters, verbose=False, **opts)
+    calls_plain = {k: f.calls[k] - c0[k] for k in c0}
+    f.speculate(True)
+    c0 = dict(f.calls); unused0 = f.spec_unused
+    b = acc.ABPG_gain(f, h, L, x0, maxitrs=iters, verbose=False, **opts)
+    calls_ahead = {k: f.calls[k] - c0[k] for k in c0}
+    for p, q in zip(a[:-1], b[:-1]):
+        np.testing.assert_array_equal(p, q)
+    assert calls_plain == calls_ahead
+    retries = calls_plain["grad"] - len(a[1])
+    assert retries > 20                                        # the runs do retry
+    assert f.spec_unused - unused0 <= 0.5 * retries + 5        # and most evaluations started ahead were used
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("solver", ["abpg", "abpg_gain"])
 def test_time_stamps_mark_when_F_was_known(acc, overlap, solver):
