@@ -1168,7 +1168,8 @@ __device__ __forceinline__ void trsm64_blk(double* __restrict__ Xs, const double
 // and `fetch(pnl, 2)` acts on the answer: if so it starts the piece's loads, which then land behind the work on the
 // current panel.  `done(pnl)` runs once the 16 columns of panel pnl of the solution are final (every thread, behind a
 // barrier): the owner publishes them and folds them into what follows while the next piece is on its way.
-// Same arithmetic as trsm64_blk.
+// Same arithmetic as trsm64_blk.  (Issuing the fold's matrix-pipe work in front of the NEXT panel's solve instead, to
+// run under its dependent vector chain, was measured slower: its LDS reads queue ahead of the solve's.)
 template <class Fetch, class Done>
 __device__ __forceinline__ bool trsm64_stream(double* __restrict__ Xs, const double* __restrict__ Lo,
                                               const double* __restrict__ tbuf, Fetch fetch, Done done) {
@@ -1886,6 +1887,23 @@ __global__ __launch_bounds__(64) void trtri_diag_kernel(const double* __restrict
     }
 }
 
+// any entry of x that is not >= 0 (NaN counts)?  One workgroup, eight independent loads in flight per thread: the
+// check sits between the Gram kernel and the factorisation on every evaluation, so its latency is on the path.
+__device__ __forceinline__ bool xcheck_bad(const double* __restrict__ x, int64_t n) {
+    bool bad = false;
+    const int64_t step = (int64_t)blockDim.x * 8;
+    int64_t i = threadIdx.x;
+    for (; i + 7 * (int64_t)blockDim.x < n; i += step) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x[i + u * (int64_t)blockDim.x];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bad |= !(v[u] >= 0.0);
+    }
+    for (; i < n; i += blockDim.x) bad |= !(x[i] >= 0.0);
+    return __syncthreads_or(bad ? 1 : 0) != 0;
+}
+
 // resets the scalars and the status flags; with x != NULL also the x >= 0 check of functions.py:45
 __global__ __launch_bounds__(1024) void zero_scalars_kernel(double* dscal, int* dflag, const double* __restrict__ x,
                                                           int64_t n, int* __restrict__ ready, int nready) {
@@ -1897,10 +1915,7 @@ __global__ __launch_bounds__(1024) void zero_scalars_kernel(double* dscal, int* 
     if (threadIdx.x < 8) dflag[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < nready; i += blockDim.x) ready[i] = 0;     // hand-off flags of the one-launch Cholesky
     if (x == nullptr) return;
-    bool bad = false;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
-        if (!(x[i] >= 0.0)) bad = true;
-    if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) dflag[FLAG_NEG_X] = 1;
+    if (xcheck_bad(x, n) && threadIdx.x == 0) dflag[FLAG_NEG_X] = 1;
 }
 
 // the same reset for the active instances of a batch (one workgroup per instance)
@@ -1913,11 +1928,7 @@ __global__ __launch_bounds__(1024) void zero_scalars_batch_kernel(const BatchIns
     if (threadIdx.x < 8) bi.dflag[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < nready; i += blockDim.x) bi.chol_ready[i] = 0;
     if (xbase == nullptr) return;
-    const double* x = xbase + (int64_t)inst * ldx;
-    bool bad = false;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x)
-        if (!(x[i] >= 0.0)) bad = true;
-    if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) bi.dflag[FLAG_NEG_X] = 1;
+    if (xcheck_bad(xbase + (int64_t)inst * ldx, n) && threadIdx.x == 0) bi.dflag[FLAG_NEG_X] = 1;
 }
 
 __global__ void set_op_kernel(GemmOp* slot, GemmOp op) { *slot = op; }
