@@ -79,14 +79,17 @@ class DOptimalBatch:
             if status[i] != _lib.OK:
                 _lib.check(status[i], "%s (instance %d)" % (what, i), assert_msg)
 
-    def func_grad(self, X, flag=2, active=None):
+    def func_grad(self, X, flag=2, active=None, out=None):
         """(f, G): f a length-K NumPy array (entries of inactive instances are nan), G a K x n tensor (rows of
-        inactive instances are left unwritten); flag 0 returns f only, flag 1 G only."""
+        inactive instances are left unwritten; `out`: an existing tensor for them); flag 0 returns f only, flag 1 G
+        only."""
         assert X.shape == (self.K, self.n) and X.is_cuda and X.dtype == torch.float64 and X.stride(1) == 1
         mask, idx = self._mask(active)
         f = (C.c_double * self.K)(*([float("nan")] * self.K))
         st = (C.c_int * self.K)()
-        G = torch.empty(self.K, self.n, dtype=torch.float64, device=self.device) if flag != 0 else None
+        G = None
+        if flag != 0:
+            G = out if out is not None else torch.empty(self.K, self.n, dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):
             self._lib.accbpg_dopt_batch_set_stream(self._h, _stream())
             rc = self._lib.accbpg_dopt_batch_func_grad(self._h, _ptr(X), X.stride(0), mask, int(flag), f, _ptr(G),
@@ -127,12 +130,14 @@ class DOptimalBatch:
         self.calls["value"] += len(idx)
         return np.array(f[:], dtype=np.float64)
 
-    def prox(self, Y, G, Ls, eps, active=None):
-        """Row i: BurgEntropySimplex(eps).div_prox_map(Y[i], G[i], Ls[i]) (Y None: prox_map)."""
+    def prox(self, Y, G, Ls, eps, active=None, out=None):
+        """Row i: BurgEntropySimplex(eps).div_prox_map(Y[i], G[i], Ls[i]) (Y None: prox_map).  Only the rows of the
+        active instances are written (`out`: an existing K x n tensor to write them into)."""
         mask, idx = self._mask(active)
         Lc = (C.c_double * self.K)(*[float(v) for v in Ls])
         st = (C.c_int * self.K)()
-        out = torch.empty(self.K, self.n, dtype=torch.float64, device=self.device)
+        if out is None:
+            out = torch.empty(self.K, self.n, dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):
             self._lib.accbpg_dopt_batch_set_stream(self._h, _stream())
             rc = self._lib.accbpg_dopt_batch_burg_simplex_div_prox(self._h, _ptr(Y), _ptr(G), self.n, Lc, float(eps),
@@ -154,12 +159,13 @@ class DOptimalBatch:
         self._raise(st, idx, "accbpg_dopt_batch_ls_terms", "Entries of x or y not positive.")
         return np.array(out[:], dtype=np.float64).reshape(self.K, 3)
 
-    def axpby(self, a, X, b, Z, active=None):
-        """Row i: a[i]*X[i] + b[i]*Z[i] with NumPy's rounding."""
+    def axpby(self, a, X, b, Z, active=None, out=None):
+        """Row i: a[i]*X[i] + b[i]*Z[i] with NumPy's rounding; only the rows of the active instances are written."""
         mask, _ = self._mask(active)
         av = (C.c_double * self.K)(*[float(v) for v in a])
         bv = (C.c_double * self.K)(*[float(v) for v in b])
-        out = torch.empty(self.K, self.n, dtype=torch.float64, device=self.device)
+        if out is None:
+            out = torch.empty(self.K, self.n, dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):
             self._lib.accbpg_dopt_batch_set_stream(self._h, _stream())
             rc = self._lib.accbpg_dopt_batch_axpby(self._h, av, _ptr(X), bv, _ptr(Z), self.n, mask, _ptr(out))
@@ -345,3 +351,135 @@ class BatchStepper:
 
     def close(self):
         self._pool.shutdown()
+
+
+def ABPG_gain_batch_steps(batch, h, L, x0, gamma, maxitrs, epsilon=1e-14, G0=1, ls_inc=1.2, ls_dec=1.2, theta_eq=True,
+                          checkdiv=False, restart=False, restart_rule='g', overlap=True):
+    """ABPG_gain (accbpg/algorithms.py:295-420) on the K instances of a ``DOptimalBatch`` in lock-step per ORACLE
+    PASS: every gradient evaluation, prox, vector pass and trial value covers the instances that need it.  The line
+    search is per instance -- each keeps its own gain, theta and retry count on the host; after a pass the instances
+    whose test failed raise their gain and take part in the next pass, the others have accepted their point and
+    wait (their rows are not touched again in this outer iteration).  Yields k after every outer iteration; returns,
+    per instance, ABPG_gain's (x, F, Gain, Gdiv, Gavg, T) -- bit-identical to ``ABPG_gain(batch.instance(i), ...)``."""
+    from .algorithms import solve_theta
+    K, n = batch.K, batch.n
+    t_start = time.time()
+    x0d, as_numpy = to_dev(x0)
+    X = x0d.reshape(1, -1).repeat(K, 1).contiguous() if x0d.dim() == 1 else x0d.clone().contiguous()
+    Z = X.clone()
+    F = np.zeros((K, maxitrs)); Gain = np.ones((K, maxitrs)) * G0; Gdiv = np.zeros((K, maxitrs))
+    Gavg = np.zeros((K, maxitrs)); T = np.zeros((K, maxitrs))
+    Gs = [float(G0)] * K
+    sumlog = [gamma * np.log(G0)] * K                                   # :342
+    theta = [1.0] * K
+    kk = [0] * K
+    Gdr = [0.0] * K
+    active = [True] * K
+    last = [-1] * K
+    result_x = [None] * K
+    eps_prox = getattr(h, "eps", 1e-8)
+    new = lambda: torch.empty(K, n, dtype=torch.float64, device=batch.device)
+    for k in range(maxitrs):
+        if not any(active):
+            break
+        ticket = batch.value_async(X, active) if overlap else None          # :347 (beside the first gradients below)
+        fx = None if overlap else batch.func_grad(X, 0, active)
+        now = time.time() - t_start
+        G_prev, theta_prev = list(Gs), list(theta)
+        for i in range(K):
+            if active[i]:
+                Gs[i] = Gs[i] / ls_dec                                      # :358
+        search = list(active)
+        Y, Gr, Zt, Xt = new(), new(), new(), new()                          # rows are written by the passes that need them
+        dzz = [0.0] * K
+        first_pass = True
+        while any(search):                                                  # :361, one pass = one trial per searching instance
+            for i in range(K):
+                if search[i] and kk[i] > 0:
+                    if theta_eq:
+                        theta[i] = solve_theta(theta_prev[i], gamma, Gs[i] / G_prev[i])
+                    else:
+                        alpha = Gs[i] / G_prev[i]
+                        theta[i] = theta_prev[i] * ((1 + alpha * (gamma - 1)) / (gamma * alpha + theta_prev[i]))
+            one_m = [1 - t for t in theta]
+            batch.axpby(one_m, X, theta, Z, search, out=Y)                  # :369
+            fy, _ = batch.func_grad(Y, 2, search, out=Gr)                   # :371
+            if first_pass:
+                if overlap:
+                    fx = batch.value_wait(ticket)
+                    now = time.time() - t_start
+                for i in range(K):
+                    if active[i]:
+                        F[i, k] = fx[i] + h.extra_Psi(None)                 # :348
+                        T[i, k] = now
+                first_pass = False
+            batch.prox(Z, Gr, [theta[i] ** (gamma - 1) * Gs[i] * L for i in range(K)], eps_prox, search, out=Zt)   # :373
+            batch.axpby(one_m, X, theta, Zt, search, out=Xt)                # :374
+            terms = batch.ls_terms(Gr, Xt, Y, Zt, Z, search)                # :377-378 and the dot of :387
+            need_value = [False] * K
+            for i in range(K):
+                if not search[i]:
+                    continue
+                lin, dxy, dzz[i] = terms[i]
+                if dzz[i] < epsilon:                                        # :379-380
+                    search[i] = False
+                    continue
+                Gdr[i] = dxy / dzz[i] / theta[i] ** gamma                   # :382
+                if checkdiv:
+                    if Gdr[i] > Gs[i]:                                      # :385
+                        Gs[i] = Gs[i] * ls_inc
+                    else:
+                        search[i] = False
+                else:
+                    need_value[i] = True
+            if any(need_value):
+                ft = batch.func_grad(Xt, 0, need_value)                     # :387
+                for i in range(K):
+                    if need_value[i]:
+                        lin = terms[i, 0]
+                        if ft[i] > fy[i] + lin + theta[i] ** gamma * Gs[i] * L * dzz[i]:
+                            Gs[i] = Gs[i] * ls_inc                          # :390
+                        else:
+                            search[i] = False
+        rest = None
+        if restart and restart_rule == 'g':
+            rest = batch.ls_terms(Gr, Xt, X, None, None, active)[:, 0]      # <g, x - x_1>, :406
+        Znext = Zt
+        for i in range(K):
+            if not active[i]:
+                continue
+            Gain[i, k] = Gs[i]
+            Gdiv[i, k] = Gdr[i]
+            sumlog[i] += np.log(Gs[i])
+            Gavg[i, k] = np.exp(sumlog[i] / (gamma + k))                    # :395-396
+            last[i] = k
+            kk[i] += 1
+            if restart:                                                     # :403-409 (no k > 0 guard)
+                if (restart_rule == 'f' and F[i, k] > F[i, k - 1]) or (restart_rule == 'g' and rest[i] > 0):
+                    theta[i] = 1.0
+                    kk[i] = 0
+                    if Znext is Zt:
+                        Znext = Zt.clone()
+                    Znext[i] = Xt[i]
+            if dzz[i] < epsilon:                                            # :412
+                active[i] = False
+                result_x[i] = Xt[i].clone()
+        X, Z = Xt, Znext
+        yield k
+    out = []
+    for i in range(K):
+        xi = result_x[i] if result_x[i] is not None else X[i].clone()
+        xi = xi.cpu().numpy() if as_numpy else xi
+        e = last[i] + 1
+        out.append((xi, F[i, :e].copy(), Gain[i, :e].copy(), Gdiv[i, :e].copy(), Gavg[i, :e].copy(), T[i, :e].copy()))
+    return out
+
+
+def ABPG_gain_batch(batch, h, L, x0, gamma, maxitrs, **kwargs):
+    """Drain ``ABPG_gain_batch_steps``: list of (x, F, Gain, Gdiv, Gavg, T), one per instance."""
+    gen = ABPG_gain_batch_steps(batch, h, L, x0, gamma, maxitrs, **kwargs)
+    while True:
+        try:
+            next(gen)
+        except StopIteration as stop:
+            return stop.value

@@ -340,14 +340,17 @@ def main():
     batch = None
     lockstep = None
     objs = [f]
-    if ipg > 1 and args.workload == "abpg" and not shard and not args.host_threads:
+    if ipg > 1 and args.workload in ("abpg", "abpg_gain") and not shard and not args.host_threads:
         # BASELINE config 4: the instances of this GPU advance in lock-step, one launch per kernel family for all of
         # them (accbpg_dopt_batch_*); results are bit-identical to solving them one after the other
-        from accbpg_and_fw_amd.batched import ABPG_batch_steps, DOptimalBatch
+        from accbpg_and_fw_amd.batched import ABPG_batch_steps, ABPG_gain_batch_steps, DOptimalBatch
         lockstep = DOptimalBatch([f.V_dev] + [make_instance(m, n, 1 + idx, device) for idx in mine[1:]])
         objs = [lockstep]
         prof_objs = []
-        gen = ABPG_batch_steps(lockstep, acc.BurgEntropySimplex(), 1.0, x0, 2, horizon)
+        if args.workload == "abpg":
+            gen = ABPG_batch_steps(lockstep, acc.BurgEntropySimplex(), 1.0, x0, 2, horizon)
+        else:
+            gen = ABPG_gain_batch_steps(lockstep, acc.BurgEntropySimplex(), 1.0, x0, 2, horizon)
 
         def advance(count=1):
             for _ in range(count):

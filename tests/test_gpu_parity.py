@@ -710,6 +710,35 @@ def test_lockstep_batch_matches_sequential(acc, O, shape, K, fused):
     batch.func_grad(torch.from_numpy(Xb).cuda(), 0, [i != 1 for i in range(K)])     # ... unless it sits out
 
 
+@pytest.mark.parametrize("shape,K,opts", [
+    ((256, 1024), 5, dict(G0=0.1)),
+    ((256, 1024), 3, dict(G0=0.1, ls_inc=1.5, ls_dec=1.1, theta_eq=False, restart=True)),
+    ((256, 2048), 4, dict(G0=0.05, checkdiv=True, restart=True, restart_rule='f')),
+    ((512, 8192), 4, dict(G0=0.1))])
+def test_lockstep_abpg_gain_matches_sequential(acc, shape, K, opts):
+    """ABPG_gain over a batch: one pass = one trial of every instance that is still searching; the line search
+    (gain, theta, retry count) is per instance on the host and only the instances whose test failed take part in
+    the next pass.  Every instance's run -- iterates, F, the gain sequence with its retries, Gdiv, Gavg -- is
+    bit-identical to ABPG_gain on that instance alone, and the instances do take different numbers of retries."""
+    from accbpg_and_fw_amd.batched import ABPG_gain_batch, DOptimalBatch
+    m, n = shape
+    Vs = [gaussian_design(m, n, 300 + 7 * i) for i in range(K)]
+    batch = DOptimalBatch(Vs)
+    assert batch.fused
+    h = acc.BurgEntropySimplex()
+    x0 = np.ones(n) / n
+    iters = 45
+    outs = ABPG_gain_batch(batch, h, 1.0, x0, 2, iters, **opts)
+    patterns = set()
+    for i in range(K):
+        ref = acc.ABPG_gain(batch.instance(i), h, 1.0, x0, gamma=2, maxitrs=iters, verbose=False, **opts)
+        for got, want in zip(outs[i][:-1], ref[:-1]):
+            np.testing.assert_array_equal(got, want)
+        gain = ref[2]
+        patterns.add(tuple(np.round(np.log(gain[1:] / gain[:-1]) / np.log(opts.get("ls_inc", 1.2)), 2)))
+    assert len(patterns) > 1 or K == 1                          # the instances did not all search alike
+
+
 def test_batched_instances_match_sequential(acc):
     """Config-4 style batch: independent instances solved concurrently from host threads on
     separate streams give exactly the results of solving them one after the other."""
