@@ -87,6 +87,7 @@ _SIGS = {
     "accbpg_dopt_profile_enable": (C.c_int, [_P, C.c_int]),
     "accbpg_dopt_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "accbpg_dopt_profile_reset": (C.c_int, [_P]),
+    "accbpg_debug_pipe_probe": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_double), _P]),
     "accbpg_mfma_f64_peak": (C.c_int, [C.c_int, C.POINTER(C.c_double), _P]),
     "accbpg_debug_chol_variant": (C.c_int, [_P, C.c_int]),
     "accbpg_debug_chol_trace": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int64)]),

@@ -354,6 +354,13 @@ extern "C" int accbpg_mfma_f64_peak(int iters, double* tflops_host, void* stream
     return mfma_peak(iters, tflops_host, (hipStream_t)stream);
 }
 
+/* Development probe (see pipe_probe_kernel): milliseconds for `iters` loop trips of 8 fp64 MFMAs (mode bit 0) and / or
+ * 128 fp64 vector FMAs (mode bit 1) per wave, one wave per SIMD on every CU. */
+extern "C" int accbpg_debug_pipe_probe(int iters, int mode, double* ms_host, void* stream) {
+    if (!ms_host || iters <= 0) return ACCBPG_ERR_ARG;
+    return pipe_probe(iters, mode, ms_host, (hipStream_t)stream);
+}
+
 extern "C" int accbpg_test_gemm(const double* A_dev, int64_t lda, const double* B_dev, int64_t ldb, double* C_dev,
                                 int64_t ldc, int64_t M, int64_t N, int64_t K, int b_kmajor, double alpha,
                                 double beta, int config, void* stream) {

@@ -1952,6 +1952,37 @@ __global__ __launch_bounds__(NTHREADS, 1) void mfma_peak_kernel(int iters, doubl
     if (s == 123.456) sink[0] = s;
 }
 
+// Development probe: do the fp64 matrix pipe and the fp64 vector pipe run at the same time?  Per loop trip every wave
+// issues `nm` independent MFMAs and `nv` independent v_fma_f64 (mode bit 0: MFMAs on, bit 1: vector FMAs on).
+__global__ __launch_bounds__(NTHREADS, 1) void pipe_probe_kernel(int iters, int mode, double* sink) {
+    d4 acc[8];
+    double va[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) va[i] = threadIdx.x * 1e-3 + i;
+    double a = 1.0 + threadIdx.x * 1e-3, b = 0.5 - threadIdx.x * 1e-3;
+    for (int it = 0; it < iters; ++it) {
+        if (mode & 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+        }
+        if (mode & 2) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(va[i]) : "v"(a), "v"(b));
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += va[i];
+    if (s == 123.456) sink[0] = s;
+}
+
 // =========================================================================================
 // host side
 // =========================================================================================
@@ -2669,6 +2700,28 @@ int launch_test_gemm(const double* A, int64_t lda, const double* B, int64_t ldb,
         return rc;
     }
     ACC_HIP(hipGetLastError());
+    return ACCBPG_OK;
+}
+
+int pipe_probe(int iters, int mode, double* ms_out, hipStream_t s) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    ACC_HIP(hipGetDevice(&dev));
+    ACC_HIP(hipGetDeviceProperties(&prop, dev));
+    double* sink = nullptr;
+    ACC_HIP(hipMalloc(&sink, 8));
+    hipEvent_t a, b;
+    ACC_HIP(hipEventCreate(&a));
+    ACC_HIP(hipEventCreate(&b));
+    pipe_probe_kernel<<<prop.multiProcessorCount, NTHREADS, 0, s>>>(iters / 10 + 1, mode, sink);
+    ACC_HIP(hipEventRecord(a, s));
+    pipe_probe_kernel<<<prop.multiProcessorCount, NTHREADS, 0, s>>>(iters, mode, sink);
+    ACC_HIP(hipEventRecord(b, s));
+    ACC_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    ACC_HIP(hipEventElapsedTime(&ms, a, b));
+    *ms_out = ms;
+    hipEventDestroy(a); hipEventDestroy(b); hipFree(sink);
     return ACCBPG_OK;
 }
 

@@ -241,6 +241,7 @@ int launch_test_gemm(const double* A, int64_t lda, const double* B, int64_t ldb,
 int build_plans(accbpg_dopt* h);
 int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, double* ms_out);
 int mfma_peak(int iters, double* tflops, hipStream_t s);
+int pipe_probe(int iters, int mode, double* ms_out, hipStream_t s);
 
 // vec_kernels.hip
 int64_t vec_ws_doubles(int64_t n);

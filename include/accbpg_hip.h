@@ -288,6 +288,10 @@ int accbpg_dopt_profile_reset(accbpg_dopt* h);
  * every CU and reports achieved TFLOP/s (used to confirm the roofline constant on the box). */
 int accbpg_mfma_f64_peak(int iters, double* tflops_host, void* stream);
 
+/* Development probe: milliseconds for `iters` loop trips of 8 fp64 MFMAs (mode bit 0) and / or 128 fp64 vector FMAs
+ * (mode bit 1) per wave, one wave per SIMD on every CU -- do the matrix and the vector pipe run at the same time? */
+int accbpg_debug_pipe_probe(int iters, int mode, double* ms_host, void* stream);
+
 /* Unit-test hook: C (MxN) <- alpha * A (MxK, row-major) * op(B) + beta*C on the MFMA engine.
  * b_kmajor != 0: B is K x N row-major; else B is N x K row-major (A * B^T). */
 int accbpg_test_gemm(const double* A_dev, int64_t lda, const double* B_dev, int64_t ldb,
