@@ -145,7 +145,6 @@ extern "C" int accbpg_dopt_batch_func_grad_begin(accbpg_dopt_batch* b, const dou
             ++act.n;
         }
     b->pend_act = act; b->pend_x = x_dev; b->pend_ldx = ldx; b->pend_flag = flag; b->pend_g = g_dev; b->pend_ldg = ldg;
-    b->pend_all = (active_host == nullptr);
     b->pend_fused = false;
     if (act.n == 0) return ACCBPG_OK;
     const bool aligned = ((reinterpret_cast<uintptr_t>(x_dev) & 15) == 0) && ((ldx & 1) == 0);

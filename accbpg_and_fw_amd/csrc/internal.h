@@ -213,7 +213,7 @@ struct accbpg_dopt_batch {
     double* pend_g = nullptr;
     int64_t pend_ldx = 0, pend_ldg = 0;
     int pend_flag = 0;
-    bool pend_all = false, pend_fused = false;
+    bool pend_fused = false;
 };
 struct BatchVals { double v[accbpg::BATCH_MAX]; };          // one scalar per instance, as a kernel argument
 

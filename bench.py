@@ -348,9 +348,9 @@ def main():
         objs = [lockstep]
         prof_objs = []
         if args.workload == "abpg":
-            gen = ABPG_batch_steps(lockstep, acc.BurgEntropySimplex(), 1.0, x0, 2, horizon)
+            gen = ABPG_batch_steps(lockstep, acc.BurgEntropySimplex(), 1.0, x0, 2, horizon, overlap=overlap)
         else:
-            gen = ABPG_gain_batch_steps(lockstep, acc.BurgEntropySimplex(), 1.0, x0, 2, horizon)
+            gen = ABPG_gain_batch_steps(lockstep, acc.BurgEntropySimplex(), 1.0, x0, 2, horizon, overlap=overlap)
 
         def advance(count=1):
             for _ in range(count):
