@@ -25,20 +25,24 @@ static int batch_init(accbpg_dopt_batch* b, const double* const* V_host, int K, 
     ACC_HIP(hipMalloc(&b->dscal_all, sizeof(double) * 24 * (size_t)K));
     ACC_HIP(hipMemset(b->dscal_all, 0, sizeof(double) * 24 * (size_t)K));
     ACC_HIP(hipHostMalloc(&b->hpin, sizeof(double) * 24 * (size_t)K, hipHostMallocDefault));
+    // instances that share a launch: as many as have their one-launch factorisations resident together
+    // (T(T+1)/2 - (T-1) workgroups each, two per CU)
+    const int T = (int)((m + NB - 1) / NB);
+    const int per_inst = std::max(1, T * (T + 1) / 2 - (T - 1));
+    b->chunk = std::max(1, std::min(K, (2 * prop.multiProcessorCount) / per_inst));
     for (int i = 0; i < K; ++i) {
         accbpg_dopt* h = new accbpg_dopt();
         b->inst.push_back(h);                                   // (destroyed with the batch from here on)
         h->V = V_host[i]; h->m = m; h->n = n; h->ldv = ldv; h->stream = b->stream;
         h->force_big = true;                                    // the tuned 256 x 128 tile also at m = 512
-        h->gram_grid_cap = std::max(1, prop.multiProcessorCount / K);   // K Gram launches share the chip
+        h->gram_grid_cap = std::max(1, prop.multiProcessorCount / b->chunk);   // the instances of a launch share the chip
         h->dscal_ext = b->dscal_all + 24 * (size_t)i;
         ACC_TRY(dopt_init(h));
     }
     accbpg_dopt* h0 = b->inst[0];
     // one launch per kernel family needs: the interior big-tile path, the one-launch Cholesky for every instance at
     // once, identical plans (same shape and alignment give identical plans)
-    bool fast = h0->big && h0->use_glds && (m % 256 == 0) && (n % 128 == 0) && h0->chol_tiles_ok &&
-                (int64_t)h0->chol_tiles_grid * K <= 2 * (int64_t)h0->num_cu && K <= BATCH_MAX;
+    bool fast = h0->big && h0->use_glds && (m % 256 == 0) && (n % 128 == 0) && h0->chol_tiles_ok && K <= BATCH_MAX;
     for (accbpg_dopt* h : b->inst) fast = fast && h->vec_ok && h->big && h->chol_tiles_ok;
     b->fast = fast;
     if (!fast) return ACCBPG_OK;
@@ -149,11 +153,16 @@ extern "C" int accbpg_dopt_batch_func_grad_begin(accbpg_dopt_batch* b, const dou
     if (act.n == 0) return ACCBPG_OK;
     const bool aligned = ((reinterpret_cast<uintptr_t>(x_dev) & 15) == 0) && ((ldx & 1) == 0);
     if (b->fast && aligned && act.n <= BATCH_MAX) {
-        ACC_TRY(launch_gram_batch(b, act, x_dev, ldx));
-        ACC_TRY(launch_cholesky_batch(b, act, flag != 0, x_dev, ldx));
-        if (flag != 0) {
-            ACC_TRY(launch_trtri_batch(b, act));
-            ACC_TRY(launch_colnorm_batch(b, act, g_dev, ldg, -1.0));
+        for (int c0 = 0; c0 < act.n; c0 += b->chunk) {          // (one chunk unless the batch is larger than the chip takes at once)
+            BatchAct part;
+            part.n = std::min(b->chunk, act.n - c0);
+            for (int a = 0; a < part.n; ++a) part.idx[a] = act.idx[c0 + a];
+            ACC_TRY(launch_gram_batch(b, part, x_dev, ldx));
+            ACC_TRY(launch_cholesky_batch(b, part, flag != 0, x_dev, ldx));
+            if (flag != 0) {
+                ACC_TRY(launch_trtri_batch(b, part));
+                ACC_TRY(launch_colnorm_batch(b, part, g_dev, ldg, -1.0));
+            }
         }
         ACC_HIP(hipMemcpyAsync(b->hpin, b->dscal_all, sizeof(double) * 24 * (size_t)b->K, hipMemcpyDeviceToHost, b->stream));
         b->pend_fused = true;

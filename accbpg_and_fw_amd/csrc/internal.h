@@ -57,7 +57,7 @@ struct TileRC {
 
 // A batch of same-shaped instances evaluated by ONE launch per kernel family (blockIdx.y = position among the
 // active instances): the per-instance pointers live in a device table, the active set travels as a kernel argument.
-constexpr int BATCH_MAX = 32;
+constexpr int BATCH_MAX = 64;
 struct BatchAct {
     int n = 0;
     int idx[BATCH_MAX] = {};
@@ -194,6 +194,8 @@ struct accbpg_dopt_batch {
     hipStream_t stream = nullptr;
     int device = 0;
     bool fast = false;                      // one launch per kernel family over the active instances
+    int chunk = 0;                          // ... at most this many instances per launch (their one-launch
+                                            // factorisations must fit the chip together)
     accbpg::BatchInst* table = nullptr;     // device, K entries
     accbpg::CholInst* chol_table[2] = {nullptr, nullptr};   // device, K entries each: without / with diagonal-block inverses
     accbpg::GemmOp* ops_all = nullptr;      // device: the merge op tables of all instances, instance after instance

@@ -662,7 +662,8 @@ def test_logical_shards_match_single_device(acc, shape, parts):
     np.testing.assert_allclose(Fb, Fa, rtol=1e-12, atol=1e-12)
 
 
-@pytest.mark.parametrize("shape,K,fused", [((512, 8192), 8, True), ((256, 1024), 5, True), ((96, 640), 4, False)])
+@pytest.mark.parametrize("shape,K,fused", [((512, 8192), 8, True), ((256, 1024), 5, True), ((96, 640), 4, False),
+                                           ((512, 1024), 20, True), ((256, 512), 1, True)])
 def test_lockstep_batch_matches_sequential(acc, O, shape, K, fused):
     """BASELINE config 4 on the chip: K instances of one shape advance in lock-step, one launch per kernel family
     for all of them (accbpg_dopt_batch_*).  Every instance's run is BIT-identical to ABPG on that instance alone
@@ -703,11 +704,13 @@ def test_lockstep_batch_matches_sequential(acc, O, shape, K, fused):
         else:
             assert np.isnan(f[i])
     # one bad instance raises what the sequential objective raises
+    bad = K - 1
     Xb = X.copy()
-    Xb[1, 7] = -1e-3
+    Xb[bad, 7] = -1e-3
     with pytest.raises(AssertionError):
         batch.func_grad(torch.from_numpy(Xb).cuda(), 0)
-    batch.func_grad(torch.from_numpy(Xb).cuda(), 0, [i != 1 for i in range(K)])     # ... unless it sits out
+    if K > 1:
+        batch.func_grad(torch.from_numpy(Xb).cuda(), 0, [i != bad for i in range(K)])   # ... unless it sits out
 
 
 @pytest.mark.parametrize("shape,K,opts", [
