@@ -326,7 +326,9 @@ def main():
         f.linear_gram(True)
     h = acc.BurgEntropySimplex()
     x0 = torch.full((n,), 1.0 / n, dtype=torch.float64, device=device)
-    steady = (not args.no_steady) and args.workload in ("abpg_gain", "abpg", "bpg") and args.steady_iters > 0
+    # (the steady-state window is 300 further iterations: only where an iteration takes tens of milliseconds)
+    steady = (not args.no_steady) and args.workload in ("abpg_gain", "abpg", "bpg") and args.steady_iters > 0 \
+        and float(m) * n <= 2.0 * 2048 * 32768
     total = args.warmup + args.steps
     horizon = max(total, args.steady_start + args.steady_iters if steady else 0) + 2
 

@@ -218,7 +218,7 @@ class _CallLog:
         return self._f.gradient(x)
 
 
-def large_gain_long(accbpg, m=2048, n=32768, seed=10, iters=64, keep=(16, 24, 32, 40, 48, 56)):
+def large_gain_long(accbpg, m=2048, n=32768, seed=10, iters=64, keep=(16, 24, 32, 40, 48, 56), name="large_gain_long"):
     """Config-2 size, the headline solver past its retry-free transient: ABPG_gain(gamma=2) for `iters` iterations
     (accbpg/algorithms.py:295-420; the inner loop :361-390 starts to retry once G has been cut below what the
     instance supports).  Stores the traces, the value every oracle call returned in call order (rejected trial
@@ -241,7 +241,47 @@ def large_gain_long(accbpg, m=2048, n=32768, seed=10, iters=64, keep=(16, 24, 32
     for k in keep:
         if k < len(F):
             out["x_%d" % k] = xk[k]
-    save("large_gain_long", **out)
+    save(name, **out)
+
+
+class _ValueTap:
+    """Pass-through that keeps the argument of selected value calls: ABPG asks for f at the iterate x_k exactly once
+    per iteration (accbpg/algorithms.py:135), so value call number k is x_k."""
+
+    def __init__(self, f, keep):
+        self._f = f
+        self._keep = set(keep)
+        self.count = 0
+        self.kept = {}
+
+    def __call__(self, x):
+        if self.count in self._keep:
+            self.kept[self.count] = x.copy()
+        self.count += 1
+        return self._f(x)
+
+    def gradient(self, x):
+        return self._f.gradient(x)
+
+    def func_grad(self, x, flag=2):
+        return self._f.func_grad(x, flag)
+
+
+def large_abpg_1000(accbpg, m=2048, n=32768, seed=10, iters=1000, keep=(250, 500, 750)):
+    """Config-2 size over the north-star's horizon: 1000 iterations of ABPG(gamma=2, theta_eq=True) -- the
+    accelerated solver whose decisions are reproducible in the reference itself -- with the iterates at k = 250, 500,
+    750 and the final one (about three hours of CPU on 8 cores)."""
+    import numpy as np
+    import time
+    f, h, L, x0 = accbpg.D_opt_design(m, n, randseed=seed)
+    tap = _ValueTap(f, keep)
+    t = time.time()
+    x, F, G, T = accbpg.ABPG(tap, h, L, x0, gamma=2.0, maxitrs=iters, theta_eq=True, verbose=True, verbskip=50)
+    print("ABPG %d its: %.1f s" % (iters, time.time() - t), flush=True)
+    out = dict(m=m, n=n, seed=seed, iters=iters, x=x, F=F, G=G, keep=np.array(sorted(tap.kept)), ref_seconds=T[-1])
+    for k, xk in tap.kept.items():
+        out["x_%d" % k] = xk
+    save("large_abpg_1000", **out)
 
 
 def traces_512(accbpg):
@@ -366,6 +406,9 @@ def main():
     ap.add_argument("--only-poisson", action="store_true")
     ap.add_argument("--only-large-long", action="store_true")
     ap.add_argument("--only-large-gain-long", action="store_true")
+    ap.add_argument("--only-large-abpg-1000", action="store_true")
+    ap.add_argument("--keep", default="16,24,32,40,48,56", help="iterations whose iterate the long ABPG_gain fixture keeps")
+    ap.add_argument("--name", default="large_gain_long")
     ap.add_argument("--m", type=int, default=2048)
     ap.add_argument("--n", type=int, default=32768)
     ap.add_argument("--iters", type=int, default=64)
@@ -382,7 +425,11 @@ def main():
         large_long(accbpg)
         return
     if args.only_large_gain_long:
-        large_gain_long(accbpg, args.m, args.n, iters=args.iters)
+        large_gain_long(accbpg, args.m, args.n, iters=args.iters, keep=tuple(int(k) for k in args.keep.split(",")),
+                        name=args.name)
+        return
+    if args.only_large_abpg_1000:
+        large_abpg_1000(accbpg)
         return
     if args.only_next:
         next_rows(accbpg)
