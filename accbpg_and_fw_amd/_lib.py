@@ -41,6 +41,11 @@ _SIGS = {
     "accbpg_tri_pack": (C.c_int, [_P, C.c_int64, _P, _P]),
     "accbpg_tri_unpack": (C.c_int, [_P, C.c_int64, _P, _P]),
     "accbpg_vec_count_bad": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "accbpg_dopt_shard_bounds": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "accbpg_shard_unique_id": (C.c_int, [_P]),
+    "accbpg_dopt_shard_create": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _P, _P, C.POINTER(_P)]),
+    "accbpg_dopt_shard_func_grad": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_double), _P]),
+    "accbpg_dopt_shard_destroy": (C.c_int, [_P]),
     "accbpg_dopt_gram_lincomb": (C.c_int, [_P, C.c_double, _P, C.c_double, _P, _P]),
     "accbpg_dopt_eval_gram": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_double), _P]),
     "accbpg_dopt_batch_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int64, C.c_int64, C.c_int64, _P, C.POINTER(_P)]),

@@ -161,6 +161,83 @@ class ShardedDOptimalObj(RSmoothFunction):
         return g
 
 
+class NativeShardedDOptimalObj(RSmoothFunction):
+    """The sharded objective with the collectives inside libaccbpg_hip.so (accbpg_dopt_shard_*, RCCL opened by
+    the library): one C call per evaluation.  Same f-protocol and results as ``ShardedDOptimalObj`` on GPUs.
+
+    V_local : this rank's columns V[:, lo:hi], (lo, hi) = shard_bounds(n, world, rank)
+    token   : the bytes of ``native_unique_id()`` made on rank 0 and handed to every rank
+              (``exchange_token`` does that through torch.distributed)
+    """
+
+    def __init__(self, V_local, n, world, rank, token):
+        import ctypes as C
+        from . import _lib
+        from .functions import DOptimalObj
+        self._lib = _lib.load()
+        self.local = DOptimalObj(V_local, _shard=True)
+        self.m, self.n = self.local.m, int(n)
+        self.lo, self.hi = shard_bounds(n, world, rank)
+        assert self.local.n == self.hi - self.lo, "V_local must hold this rank's columns"
+        self.device = self.local.device
+        self.world, self.rank = int(world), int(rank)
+        self.calls = {"value": 0, "grad": 0}
+        self.H = None
+        buf = (C.c_ubyte * len(token)).from_buffer_copy(bytes(token))
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self._lib.accbpg_dopt_shard_create(self.local._h, self.n, self.world, self.rank, buf, None, C.byref(h))
+        _lib.check(rc, "accbpg_dopt_shard_create")
+        self._s = h
+
+    def __del__(self):
+        s, self._s = getattr(self, "_s", None), None
+        if s:
+            self._lib.accbpg_dopt_shard_destroy(s)
+
+    def __call__(self, x):
+        return self.func_grad(x, flag=0)
+
+    def gradient(self, x):
+        return self.func_grad(x, flag=1)
+
+    def func_grad(self, x, flag=2):
+        import ctypes as C
+        from . import _lib
+        from .functions import _ptr, _stream, to_dev, from_dev
+        xd, was_np = to_dev(x)
+        assert xd.numel() == self.n, "DOptimalObj: x.size not equal to n"
+        fval = C.c_double(0.0)
+        g = torch.empty(self.n, dtype=torch.float64, device=self.device) if flag != 0 else None
+        with torch.cuda.device(self.device):
+            self._lib.accbpg_dopt_set_stream(self.local._h, _stream())
+            rc = self._lib.accbpg_dopt_shard_func_grad(self._s, _ptr(xd), flag, C.byref(fval),
+                                                       _ptr(g) if g is not None else None)
+        _lib.check(rc, "accbpg_dopt_shard_func_grad")
+        self.calls["value" if flag == 0 else "grad"] += 1
+        if flag == 0:
+            return fval.value
+        g = from_dev(g, was_np)
+        return g if flag == 1 else (fval.value, g)
+
+
+def native_unique_id():
+    """Rendezvous token of the library's own RCCL communicator (bytes; make it on rank 0)."""
+    import ctypes as C
+    from . import _lib
+    buf = (C.c_ubyte * 128)()
+    _lib.check(_lib.load().accbpg_shard_unique_id(buf), "accbpg_shard_unique_id")
+    return bytes(buf)
+
+
+def exchange_token(rank, group=None):
+    """Rank 0 makes the token, torch.distributed hands it to everyone."""
+    import torch.distributed as dist
+    box = [native_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return box[0]
+
+
 class LogicalShards:
     """P shards of one instance on ONE device, the all-reduce replaced by an in-process sum: the
     test mode for the sharded arithmetic where fewer than two GPUs are visible."""
@@ -218,3 +295,10 @@ def make_sharded(V_local, m, n, rank, world, device=None, group=None):
     assert V_local.shape == (m, hi - lo), "V_local must hold this rank's columns"
     local = DOptimalObj(V_local, _shard=True)
     return ShardedDOptimalObj(local, m, n, lo, hi, local.device, reduce=_DistSum(group), world=world)
+
+
+def make_sharded_native(V_local, m, n, rank, world, group=None):
+    """As make_sharded, with the collectives inside the library (its own RCCL communicator)."""
+    lo, hi = shard_bounds(n, world, rank)
+    assert V_local.shape == (m, hi - lo), "V_local must hold this rank's columns"
+    return NativeShardedDOptimalObj(V_local, n, world, rank, exchange_token(rank, group))

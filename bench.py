@@ -73,6 +73,9 @@ def parse(argv=None):
     ap.add_argument("--steady-start", type=int, default=100, help="first iteration of the steady-state window")
     ap.add_argument("--steady-iters", type=int, default=200, help="iterations timed in the steady-state window")
     ap.add_argument("--no-steady", action="store_true")
+    ap.add_argument("--library-collectives", action="store_true",
+                    help="shard mode: the all-reduce / all-gather inside libaccbpg_hip.so (accbpg_dopt_shard_*, its own "
+                         "RCCL communicator) instead of torch.distributed")
     ap.add_argument("--no-overlap", action="store_true",
                     help="evaluate F[k] = f(x) on the solver's own stream instead of beside the gradient evaluation")
     ap.add_argument("--speculation", action="store_true",
@@ -306,7 +309,11 @@ def main():
         gen = torch.Generator(device=device)
         gen.manual_seed(1000 + rank)
         V = torch.randn(m, hi - lo, dtype=torch.float64, device=device, generator=gen)
-        f = make_sharded(V, m, n, rank, world)
+        if args.library_collectives:
+            from accbpg_and_fw_amd.sharded import make_sharded_native
+            f = make_sharded_native(V, m, n, rank, world)
+        else:
+            f = make_sharded(V, m, n, rank, world)
         prof_objs = [f.local]
     elif m * n * 8 > (4 << 30):
         # one GPU's worth of a config-5-sized instance: generated on the device like the shards
@@ -512,7 +519,8 @@ def main():
         ninst = 1 if shard else world * ipg
         value = ninst * args.steps / elapsed
         if shard:
-            layout = "ONE instance, design points sharded over the GPUs, one RCCL all-reduce of the Gram matrix per evaluation"
+            layout = "ONE instance, design points sharded over the GPUs, one RCCL all-reduce of the Gram matrix per evaluation" \
+                + (" (collectives inside the library)" if args.library_collectives else "")
         elif lockstep is not None:
             layout = ("%d independent instances per GPU advancing in lock-step (one launch per kernel family for all of "
                       "them%s), dealt round-robin over the ranks" % (ipg, "" if lockstep.fused else "; NOT fused at this shape"))

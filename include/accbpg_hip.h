@@ -92,6 +92,24 @@ int accbpg_tri_pack(const double* G_dev, int64_t m, double* packed_dev, void* st
 int accbpg_tri_unpack(const double* packed_dev, int64_t m, double* G_dev, void* stream);
 int accbpg_vec_count_bad(const double* x_dev, int64_t n, double* count_dev, void* stream);
 
+/* The sharded evaluation as one call, with the collectives inside the library (SURVEY.md 8(b) "dopt_shard_*",
+ * 8(e).2): RCCL (librccl.so.1) is opened at run time.  `local` is a handle over this rank's columns V[:, lo:hi],
+ * lo and hi from accbpg_dopt_shard_bounds (contiguous slices whose lengths differ by at most one).  Either `comm`
+ * is an RCCL communicator of the caller's (an ncclComm_t; used, not owned), or it is null and the communicator
+ * is made from the ACCBPG_SHARD_ID_BYTES-byte token that accbpg_shard_unique_id gave rank 0 and rank 0 handed round.
+ * accbpg_dopt_shard_func_grad evaluates f(x) = -log det(V diag(x) V^T) (accbpg/functions.py:40-60) at the whole
+ * length-n device vector x, which every rank holds: one all-reduce of the packed Gram triangle (+ the x >= 0
+ * violation count) and, for flags 1 and 2, one all-gather of the gradient slices; g_dev receives the whole
+ * gradient on every rank.  Return codes as accbpg_dopt_func_grad, the same on every rank. */
+#define ACCBPG_SHARD_ID_BYTES 128
+typedef struct accbpg_dopt_shard accbpg_dopt_shard;
+int accbpg_dopt_shard_bounds(int64_t n, int world, int rank, int64_t* lo, int64_t* hi);
+int accbpg_shard_unique_id(void* id_out);
+int accbpg_dopt_shard_create(accbpg_dopt* local, int64_t n, int world, int rank, const void* unique_id,
+                             void* comm, accbpg_dopt_shard** out);
+int accbpg_dopt_shard_func_grad(accbpg_dopt_shard* s, const double* x_dev, int flag, double* f_host, double* g_dev);
+int accbpg_dopt_shard_destroy(accbpg_dopt_shard* s);
+
 /* Linearity of the Gram matrix in x (an extension with no reference counterpart; opt-in from the
  * Python side): out <- a*G1 + b*G2 is the Gram matrix at a*x1 + b*x2 when G1, G2 are those at x1, x2;
  * accbpg_dopt_eval_gram finishes func_grad from a Gram matrix (Cholesky, log det, gradient). */

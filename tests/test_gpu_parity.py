@@ -662,6 +662,45 @@ def test_logical_shards_match_single_device(acc, shape, parts):
     np.testing.assert_allclose(Fb, Fa, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("shape", [(96, 1001), (1024, 4096), (2048, 8192)])
+def test_library_side_collectives_at_world_one(acc, shape):
+    """accbpg_dopt_shard_* (the sharded evaluation with RCCL inside the library) on a communicator of one rank, which
+    is what one GPU allows: the all-reduce and all-gather are identities, so f and g are bit for bit those of the
+    staged evaluation with one in-process shard (and those of the unsharded objective to rounding: the staged path
+    inverts the factor's diagonal blocks in a launch of its own), the assertion on x >= 0 is the reference's, and a
+    solver runs on it unchanged.  (The message layout and the assembly of unequal slices are the ones
+    tests/test_sharded_cpu.py covers with two ranks.)"""
+    from accbpg_and_fw_amd.sharded import LogicalShards, NativeShardedDOptimalObj, native_unique_id
+    m, n = shape
+    V = gaussian_design(m, n, 12)
+    rng = np.random.RandomState(4)
+    x = rng.rand(n) + 0.01
+    x /= x.sum()
+    f = acc.DOptimalObj(V)
+    fs = NativeShardedDOptimalObj(torch.from_numpy(V).cuda(), n, 1, 0, native_unique_id())
+    f1, g1 = f.func_grad(x, 2)
+    f2, g2 = fs.func_grad(x, 2)
+    f3, g3 = LogicalShards(V, 1).func_grad(x, 2)
+    assert f2 == f3 and f1 == f2
+    np.testing.assert_array_equal(g2, g3)
+    np.testing.assert_allclose(g2, g1, rtol=1e-13)
+    assert fs(x) == f2
+    np.testing.assert_array_equal(fs.gradient(x), g2)
+    for bad_value in (-1e-9, np.nan):
+        xb = x.copy()
+        xb[n - 2] = bad_value
+        with pytest.raises(AssertionError):
+            fs(xb)
+    with pytest.raises(ValueError):
+        fs(np.zeros(n))                                          # Gram matrix zero: not positive definite
+    h = acc.BurgEntropySimplex()
+    x0 = np.ones(n) / n
+    xa, Fa, Ga, Ta = acc.ABPG(f, h, 1.0, x0, gamma=2, maxitrs=10, verbose=False)
+    xb, Fb, Gb, Tb = acc.ABPG(fs, h, 1.0, x0, gamma=2, maxitrs=10, verbose=False)
+    assert np.max(np.abs(xa - xb)) < 1e-12
+    np.testing.assert_allclose(Fb, Fa, rtol=1e-12, atol=1e-12)
+
+
 @pytest.mark.parametrize("shape,K,fused", [((512, 8192), 8, True), ((256, 1024), 5, True), ((96, 640), 4, False),
                                            ((512, 1024), 20, True), ((256, 512), 1, True)])
 def test_lockstep_batch_matches_sequential(acc, O, shape, K, fused):
