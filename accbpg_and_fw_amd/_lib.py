@@ -46,6 +46,7 @@ _SIGS = {
     "accbpg_dopt_shard_create": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _P, _P, C.POINTER(_P)]),
     "accbpg_dopt_shard_func_grad": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_double), _P]),
     "accbpg_dopt_shard_destroy": (C.c_int, [_P]),
+    "accbpg_debug_shard_pad": (C.c_int, [_P, C.c_int64]),
     "accbpg_dopt_gram_lincomb": (C.c_int, [_P, C.c_double, _P, C.c_double, _P, _P]),
     "accbpg_dopt_eval_gram": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_double), _P]),
     "accbpg_dopt_batch_create": (C.c_int, [C.POINTER(_P), C.c_int, C.c_int64, C.c_int64, C.c_int64, _P, C.POINTER(_P)]),

@@ -225,3 +225,16 @@ extern "C" int accbpg_dopt_shard_func_grad(accbpg_dopt_shard* s, const double* x
     }
     return ACCBPG_OK;
 }
+
+/* Test hook: gather the gradient slices through the padded staging buffer (the path of slice lengths that differ
+ * between ranks) with `extra` more entries per rank than the longest slice needs, whatever n and the world size are. */
+extern "C" int accbpg_debug_shard_pad(accbpg_dopt_shard* s, int64_t extra) {
+    if (!s || extra < 0) return ACCBPG_ERR_ARG;
+    ACC_HIP(hipSetDevice(s->local->device));
+    ACC_HIP(hipStreamSynchronize(s->local->stream));
+    hipFree(s->gath);
+    s->gath = nullptr;
+    s->piece = (s->n + s->world - 1) / s->world + extra;
+    ACC_HIP(hipMalloc(&s->gath, sizeof(double) * (size_t)s->world * s->piece));
+    return ACCBPG_OK;
+}

@@ -109,6 +109,9 @@ int accbpg_dopt_shard_create(accbpg_dopt* local, int64_t n, int world, int rank,
                              void* comm, accbpg_dopt_shard** out);
 int accbpg_dopt_shard_func_grad(accbpg_dopt_shard* s, const double* x_dev, int flag, double* f_host, double* g_dev);
 int accbpg_dopt_shard_destroy(accbpg_dopt_shard* s);
+/* test hook: gather the gradient through the padded staging buffer (the path of unequal slices), `extra` spare
+ * entries per rank */
+int accbpg_debug_shard_pad(accbpg_dopt_shard* s, int64_t extra);
 
 /* Linearity of the Gram matrix in x (an extension with no reference counterpart; opt-in from the
  * Python side): out <- a*G1 + b*G2 is the Gram matrix at a*x1 + b*x2 when G1, G2 are those at x1, x2;

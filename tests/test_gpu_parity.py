@@ -819,6 +819,12 @@ def test_library_side_collectives_at_world_one(acc, shape):
     np.testing.assert_allclose(g2, g1, rtol=1e-13)
     assert fs(x) == f2
     np.testing.assert_array_equal(fs.gradient(x), g2)
+    # the gather of slices of unequal length (padded staging buffer, per-rank copies), forced here
+    from accbpg_and_fw_amd import _lib
+    _lib.check(_lib.load().accbpg_debug_shard_pad(fs._s, 3), "accbpg_debug_shard_pad")
+    f4, g4 = fs.func_grad(x, 2)
+    assert f4 == f2
+    np.testing.assert_array_equal(g4, g2)
     for bad_value in (-1e-9, np.nan):
         xb = x.copy()
         xb[n - 2] = bad_value
