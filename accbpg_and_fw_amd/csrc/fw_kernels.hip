@@ -133,46 +133,79 @@ __global__ __launch_bounds__(FB) void fw_xupdate_gather_kernel(double* __restric
 // hv = H vp, one wave per row of H          (np.dot(H, V[:,i]), D_opt_alg.py:78,166,175)
 __global__ __launch_bounds__(FB) void fw_gemv_h_kernel(const double* __restrict__ H, int64_t m,
                                                       const double* __restrict__ vp, double* __restrict__ hv) {
+    // one wave per PAIR of rows (twice the loads in flight per wave; the per-row summation order is that of one
+    // row per wave)
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * (FB / 64) + (threadIdx.x >> 6);
+    const int64_t row = 2 * ((int64_t)blockIdx.x * (FB / 64) + (threadIdx.x >> 6));
     if (row >= m) return;
+    const bool two = row + 1 < m;
     const double* hr = H + row * m;
-    double s = 0.0;
+    const double* hq = two ? hr + m : hr;
+    double s = 0.0, t = 0.0;
     if ((m & 1) == 0) {
-        // 16-byte loads, four independent accumulators (H rows are 16-byte aligned when m is even)
+        // 16-byte loads, four independent accumulators per row (H rows are 16-byte aligned when m is even)
         const double2* h2 = reinterpret_cast<const double2*>(hr);
+        const double2* q2 = reinterpret_cast<const double2*>(hq);
         const double2* v2 = reinterpret_cast<const double2*>(vp);
         const int64_t n2 = m >> 1;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
         int64_t c = lane;
         for (; c + 64 < n2; c += 128) {
-            const double2 a = h2[c], b = h2[c + 64], x = v2[c], y = v2[c + 64];
+            const double2 a = h2[c], b = h2[c + 64], p = q2[c], q = q2[c + 64], x = v2[c], y = v2[c + 64];
             s0 = fma(a.x, x.x, s0); s1 = fma(a.y, x.y, s1);
             s2 = fma(b.x, y.x, s2); s3 = fma(b.y, y.y, s3);
+            t0 = fma(p.x, x.x, t0); t1 = fma(p.y, x.y, t1);
+            t2 = fma(q.x, y.x, t2); t3 = fma(q.y, y.y, t3);
         }
         for (; c < n2; c += 64) {
-            const double2 a = h2[c], x = v2[c];
+            const double2 a = h2[c], p = q2[c], x = v2[c];
             s0 = fma(a.x, x.x, s0); s1 = fma(a.y, x.y, s1);
+            t0 = fma(p.x, x.x, t0); t1 = fma(p.y, x.y, t1);
         }
         s = (s0 + s1) + (s2 + s3);
+        t = (t0 + t1) + (t2 + t3);
     } else {
-        for (int64_t c = lane; c < m; c += 64) s = fma(hr[c], vp[c], s);
+        for (int64_t c = lane; c < m; c += 64) {
+            s = fma(hr[c], vp[c], s);
+            t = fma(hq[c], vp[c], t);
+        }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    if (lane == 0) hv[row] = s;
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off);
+        t += __shfl_down(t, off);
+    }
+    if (lane == 0) {
+        hv[row] = s;
+        if (two) hv[row + 1] = t;
+    }
 }
 
-// H <- (H + hcoef*outer(hv,hv)) / hdiv       (D_opt_alg.py:79,167,176)
+// H <- (H + hcoef*outer(hv,hv)) / hdiv       (D_opt_alg.py:79,167,176); a row per workgroup pass
 __global__ __launch_bounds__(FB) void fw_rank1_kernel(double* __restrict__ H, int64_t m,
                                                      const double* __restrict__ hv, double hcoef, double hdiv) {
-    const int64_t total = m * m;
-    const int64_t stride = (int64_t)gridDim.x * FB;
-    for (int64_t e = (int64_t)blockIdx.x * FB + threadIdx.x; e < total; e += stride) {
-        const int64_t r = e / m, c = e - r * m;
-        const double o = hv[r] * hv[c];
-        const double t = hcoef * o;
-        H[e] = (H[e] + t) / hdiv;
+    for (int64_t r = blockIdx.x; r < m; r += gridDim.x) {
+        const double hr = hv[r];
+        double* row = H + r * m;
+        if ((m & 1) == 0) {
+            double2* row2 = reinterpret_cast<double2*>(row);
+            const double2* hv2 = reinterpret_cast<const double2*>(hv);
+            for (int64_t c = threadIdx.x; c < (m >> 1); c += FB) {
+                double2 a = row2[c];
+                const double2 b = hv2[c];
+                const double o0 = hr * b.x, o1 = hr * b.y;
+                const double t0 = hcoef * o0, t1 = hcoef * o1;
+                a.x = (a.x + t0) / hdiv;
+                a.y = (a.y + t1) / hdiv;
+                row2[c] = a;
+            }
+        } else {
+            for (int64_t c = threadIdx.x; c < m; c += FB) {
+                const double o = hr * hv[c];
+                const double t = hcoef * o;
+                row[c] = (row[c] + t) / hdiv;
+            }
+        }
     }
 }
 
@@ -482,8 +515,9 @@ extern "C" int accbpg_fw_update(accbpg_dopt* h, int64_t p, double xscale, double
     int64_t gb = (std::max(n, m) + FB - 1) / FB;
     if (gb > 1024) gb = 1024;
     fw_xupdate_gather_kernel<<<(int)gb, FB, 0, h->stream>>>(h->fw_x, n, p, xscale, xadd, h->V, h->ldv, m, vp);
-    fw_gemv_h_kernel<<<(int)((m + FB / 64 - 1) / (FB / 64)), FB, 0, h->stream>>>(h->fw_H, m, vp, h->fw_hv);
-    int64_t rb = (m * m + FB - 1) / FB;
+    const int64_t pairs = (m + 1) / 2;
+    fw_gemv_h_kernel<<<(int)((pairs + FB / 64 - 1) / (FB / 64)), FB, 0, h->stream>>>(h->fw_H, m, vp, h->fw_hv);
+    int64_t rb = m;
     if (rb > 4096) rb = 4096;
     fw_rank1_kernel<<<(int)rb, FB, 0, h->stream>>>(h->fw_H, m, h->fw_hv, hcoef, hdiv);
     const int ns = fw_nsplit(h);
