@@ -284,6 +284,33 @@ def large_abpg_1000(accbpg, m=2048, n=32768, seed=10, iters=1000, keep=(250, 500
     save("large_abpg_1000", **out)
 
 
+def large_fw_long(accbpg, m=2048, n=32768, seed=10, iters=1000):
+    """Config 3 (BASELINE.json): D_opt_FW and D_opt_FW_away at (2048, 32768) for 1000 iterations from x0 = 1/n
+    (accbpg/D_opt_alg.py:9-88, 91-187): final iterates and the per-iteration traces (objective, dual gap /
+    positive and negative gaps), which pin every step choice along the way."""
+    import time
+    f, h, L, x0 = accbpg.D_opt_design(m, n, randseed=seed)
+    V = f.H
+    t = time.time()
+    xf, F, SP, SN, T = accbpg.D_opt_FW(V, x0, 1e-8, iters, verbose=True, verbskip=100)
+    print("FW %d its: %.1f s" % (iters, time.time() - t), flush=True)
+    t = time.time()
+    xa, Fa, SPa, SNa, Ta = accbpg.D_opt_FW_away(V, x0, 1e-8, iters, verbose=True, verbskip=100)
+    print("FW away %d its: %.1f s" % (iters, time.time() - t), flush=True)
+    save("large_fw_long", m=m, n=n, seed=seed, iters=iters, fw_x=xf, fw_F=F, fw_SP=SP, fw_SN=SN,
+         away_x=xa, away_F=Fa, away_SP=SPa, away_SN=SNa)
+
+
+def large_bpg_long(accbpg, m=2048, n=32768, seed=10, iters=300):
+    """Config-2 size: BPG with line search for 300 iterations (accbpg/algorithms.py:11-72)."""
+    import time
+    f, h, L, x0 = accbpg.D_opt_design(m, n, randseed=seed)
+    t = time.time()
+    x, F, Ls, T = accbpg.BPG(f, h, L, x0, maxitrs=iters, linesearch=True, verbose=True, verbskip=25)
+    print("BPG-LS %d its: %.1f s" % (iters, time.time() - t), flush=True)
+    save("large_bpg_long", m=m, n=n, seed=seed, iters=iters, x=x, F=F, Ls=Ls, ref_seconds=T[-1])
+
+
 def traces_512(accbpg):
     """1000-iteration traces at the config-4 instance size (about 10 minutes of CPU)."""
     f, h, L, x0 = accbpg.D_opt_design(512, 8192, randseed=10)
@@ -407,6 +434,8 @@ def main():
     ap.add_argument("--only-large-long", action="store_true")
     ap.add_argument("--only-large-gain-long", action="store_true")
     ap.add_argument("--only-large-abpg-1000", action="store_true")
+    ap.add_argument("--only-large-fw-long", action="store_true")
+    ap.add_argument("--only-large-bpg-long", action="store_true")
     ap.add_argument("--keep", default="16,24,32,40,48,56", help="iterations whose iterate the long ABPG_gain fixture keeps")
     ap.add_argument("--name", default="large_gain_long")
     ap.add_argument("--m", type=int, default=2048)
@@ -430,6 +459,12 @@ def main():
         return
     if args.only_large_abpg_1000:
         large_abpg_1000(accbpg)
+        return
+    if args.only_large_fw_long:
+        large_fw_long(accbpg)
+        return
+    if args.only_large_bpg_long:
+        large_bpg_long(accbpg)
         return
     if args.only_next:
         next_rows(accbpg)

@@ -711,6 +711,49 @@ def test_large_fw_2048x32768(large, acc):
     _close(F, gd["away_F"], 1e-8); _close(SP, gd["away_SP"], 1e-9)
 
 
+def test_large_fw_1000_iterations_2048x32768(large, acc):
+    """BASELINE config 3 at full length: D_opt_FW and D_opt_FW_away at (2048,32768) for 1000 iterations against the
+    real reference (oracle/gen_golden.py --only-large-fw-long; accbpg/D_opt_alg.py:9-88, 91-187).  The traces hold
+    the objective and the gaps of every iteration, so every vertex choice and step length along the way is pinned.
+    Measured: l_inf(x) 1.7e-18 / 1.8e-18, objective traces to 3e-15 / 1e-14, gap traces to 6e-14 / 5e-14."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "large_fw_long.npz")):
+        pytest.skip("tests/golden/large_fw_long.npz not generated")
+    f, h, L, x0, _ = large
+    gd = golden("large_fw_long")
+    iters = int(gd["iters"])
+    x, F, SP, SN, T = acc.D_opt_FW(f, x0, 1e-8, iters, verbose=False)
+    print("FW: l_inf %.2e, F %.2e, SP %.2e" % (np.max(np.abs(x - gd["fw_x"])), np.max(np.abs(F - gd["fw_F"]) / (1 + np.abs(gd["fw_F"]))),
+                                              np.max(np.abs(SP - gd["fw_SP"]) / (1e-30 + np.abs(gd["fw_SP"])))))
+    assert len(F) == len(gd["fw_F"])
+    assert np.max(np.abs(x - gd["fw_x"])) < 1e-9
+    _close(F, gd["fw_F"], 1e-9); _close(SP, gd["fw_SP"], 1e-7); _close(SN, gd["fw_SN"], 1e-7)
+    x, F, SP, SN, T = acc.D_opt_FW_away(f, x0, 1e-8, iters, verbose=False)
+    print("away: l_inf %.2e, F %.2e, SP %.2e" % (np.max(np.abs(x - gd["away_x"])), np.max(np.abs(F - gd["away_F"]) / (1 + np.abs(gd["away_F"]))),
+                                                np.max(np.abs(SP - gd["away_SP"]) / (1e-30 + np.abs(gd["away_SP"])))))
+    assert len(F) == len(gd["away_F"])
+    assert np.max(np.abs(x - gd["away_x"])) < 1e-9
+    _close(F, gd["away_F"], 1e-8); _close(SP, gd["away_SP"], 1e-7); _close(SN, gd["away_SN"], 1e-7)
+
+
+def test_large_bpg_ls_300_iterations_2048x32768(large, acc):
+    """BPG with line search at (2048,32768) for 300 iterations against the real reference (oracle/gen_golden.py
+    --only-large-bpg-long; accbpg/algorithms.py:11-72): the same L_k sequence (every accept/reject decision of the
+    backtracking search), F[k] to 1e-9, the final iterate to l_inf < 1e-9."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "large_bpg_long.npz")):
+        pytest.skip("tests/golden/large_bpg_long.npz not generated")
+    f, h, L, x0, _ = large
+    gd = golden("large_bpg_long")
+    iters = int(gd["iters"])
+    x, F, Ls, T = acc.BPG(f, h, L, x0, maxitrs=iters, linesearch=True, verbose=False)
+    print("BPG-LS: l_inf %.2e, F %.2e" % (np.max(np.abs(x - gd["x"])), np.max(np.abs(F - gd["F"]) / (1 + np.abs(gd["F"])))))
+    assert len(F) == iters
+    _close(Ls, gd["Ls"], 1e-12)
+    _close(F, gd["F"], 1e-9)
+    assert np.max(np.abs(x - gd["x"])) < 1e-9
+
+
 # ------------------------------------------------------------------ one-launch Cholesky (tile owners)
 @pytest.mark.parametrize("m", [64, 100, 128, 512, 520, 1000, 1024, 1984, 2048])
 def test_tile_cholesky_matches_step_kernels(acc, O, m):
