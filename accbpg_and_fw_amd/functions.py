@@ -196,6 +196,9 @@ class DOptimalObj(RSmoothFunction):
                                                   C.c_void_p(self._side.cuda_stream), C.byref(h2), 1)
             _lib.check(rc, "accbpg_dopt_create")
             self._h2 = h2
+            # its evaluations run beside the gradient evaluation of the solver's own stream: a launch per block
+            # column leaves that stream its compute units (bit-identical results)
+            self._lib.accbpg_dopt_factor_in_small_launches(h2, 1)
             if self._prof:
                 self._lib.accbpg_dopt_profile_enable(self._h2, 1)
         return self._h2

@@ -323,6 +323,12 @@ int accbpg_test_gemm(const double* A_dev, int64_t lda, const double* B_dev, int6
  * others drop global loads / LDS staging / the barrier / fragment reads and produce wrong data
  * into scratch).  Average milliseconds per launch over `iters` launches. */
 int accbpg_debug_gram_variant(accbpg_dopt* h, const double* x_dev, int variant, int iters, double* ms_host);
+/* For a handle whose evaluations run BESIDE another stream's MFMA-bound launches (the value evaluation the solvers
+ * start next to a gradient evaluation, accbpg/algorithms.py:135 beside :148): factor with one launch per 64-wide
+ * block column -- a few workgroups at a time -- instead of the one-launch kernel, whose waiting workgroups would
+ * hold the compute units the other stream needs.  Same arithmetic in the same order: bit-identical results. */
+int accbpg_dopt_factor_in_small_launches(accbpg_dopt* h, int on);
+
 /* Timing ablation bits for the Cholesky step kernel (development aid; 0 = product behaviour):
  * 1 skip the diagonal-block factorisation, 2 skip the panel solve, 4 skip the MFMA products; 8, 16, 32 switch
  * off the row solves / MFMA updates / 16x16 factor inside the 64x64 factorisation.  256 / 512 select the
