@@ -375,8 +375,11 @@ extern "C" int accbpg_test_gemm(const double* A_dev, int64_t lda, const double* 
  * arithmetic, bit-identical results.  Measured at config 2: ABPG_gain 50.6 -> 52.0 it/s in the steady state,
  * 88.8 -> 92.2 in the transient window. */
 extern "C" int accbpg_dopt_factor_in_small_launches(accbpg_dopt* h, int on) {
-    if (!h) return ACCBPG_ERR_ARG;
-    h->chol_tiles_off = on != 0;
+    if (!h || on < 0 || on > 2) return ACCBPG_ERR_ARG;
+    // 2 = where it pays: only a factorisation with at least a workgroup per compute unit crowds the other stream out
+    // (m > 1408 on 256 CUs); below that the single launch is the faster neighbour too ((512,8192): 1507 against 1464 it/s)
+    const int64_t T = (h->m + NB - 1) / NB;
+    h->chol_tiles_off = on == 1 || (on == 2 && T * (T + 1) / 2 >= h->num_cu);
     return ACCBPG_OK;
 }
 

@@ -198,7 +198,7 @@ class DOptimalObj(RSmoothFunction):
             self._h2 = h2
             # its evaluations run beside the gradient evaluation of the solver's own stream: a launch per block
             # column leaves that stream its compute units (bit-identical results)
-            self._lib.accbpg_dopt_factor_in_small_launches(h2, 1)
+            self._lib.accbpg_dopt_factor_in_small_launches(h2, 2)
             if self._prof:
                 self._lib.accbpg_dopt_profile_enable(self._h2, 1)
         return self._h2

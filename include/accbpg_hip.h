@@ -326,7 +326,9 @@ int accbpg_debug_gram_variant(accbpg_dopt* h, const double* x_dev, int variant, 
 /* For a handle whose evaluations run BESIDE another stream's MFMA-bound launches (the value evaluation the solvers
  * start next to a gradient evaluation, accbpg/algorithms.py:135 beside :148): factor with one launch per 64-wide
  * block column -- a few workgroups at a time -- instead of the one-launch kernel, whose waiting workgroups would
- * hold the compute units the other stream needs.  Same arithmetic in the same order: bit-identical results. */
+ * hold the compute units the other stream needs.  Same arithmetic in the same order: bit-identical results.
+ * on: 0 = one launch (default), 1 = small launches, 2 = small launches where the one launch would put at least a
+ * workgroup on every compute unit (m > 1408 on 256 CUs), one launch below that. */
 int accbpg_dopt_factor_in_small_launches(accbpg_dopt* h, int on);
 
 /* Timing ablation bits for the Cholesky step kernel (development aid; 0 = product behaviour):
