@@ -711,6 +711,28 @@ def test_large_fw_2048x32768(large, acc):
     _close(F, gd["away_F"], 1e-8); _close(SP, gd["away_SP"], 1e-9)
 
 
+def test_factor_in_small_launches_is_the_same_arithmetic(acc):
+    """accbpg_dopt_factor_in_small_launches (what the side handle of the overlapped value evaluation uses): every mode
+    returns the value and gradient of the default bit for bit; mode 2 switches by size; a bad mode is refused."""
+    from accbpg_and_fw_amd import _lib
+    L = _lib.load()
+    for m, n in [(1536, 4096), (512, 2048)]:
+        V = gaussian_design(m, n, 21)
+        rng = np.random.RandomState(m)
+        x = rng.rand(n) + 0.01
+        x /= x.sum()
+        f = acc.DOptimalObj(V)
+        base_f, base_g = f.func_grad(x, 2)
+        for mode in (1, 2, 0):
+            assert L.accbpg_dopt_factor_in_small_launches(f._h, mode) == 0
+            fv, g = f.func_grad(x, 2)
+            assert fv == base_f
+            np.testing.assert_array_equal(g, base_g)
+            assert f(x) == base_f
+        assert L.accbpg_dopt_factor_in_small_launches(f._h, 3) == 4      # ACCBPG_ERR_ARG
+        assert L.accbpg_dopt_factor_in_small_launches(None, 1) == 4
+
+
 def test_large_fw_1000_iterations_2048x32768(large, acc):
     """BASELINE config 3 at full length: D_opt_FW and D_opt_FW_away at (2048,32768) for 1000 iterations against the
     real reference (oracle/gen_golden.py --only-large-fw-long; accbpg/D_opt_alg.py:9-88, 91-187).  The traces hold
