@@ -41,8 +41,14 @@ class _FWState:
         _lib.check(rc, "accbpg_fw_probe_step")
         return pr
 
+    def logdet_ring(self, depth, small_launches=2):
+        """How many side factorisations of ``probe(refresh_logdet=2)`` may be in flight, and how they run."""
+        with torch.cuda.device(self.obj.device):
+            rc = self.lib.accbpg_fw_logdet_ring(self.h, int(depth), int(small_launches))
+        _lib.check(rc, "accbpg_fw_logdet_ring")
+
     def flush_logdet(self):
-        """log det(H) of the last ``probe(refresh_logdet=2)`` call (see accbpg_fw_logdet_flush)."""
+        """log det(H) of the oldest ``probe(refresh_logdet=2)`` call still in flight (see accbpg_fw_logdet_flush)."""
         out = C.c_double(0.0)
         with torch.cuda.device(self.obj.device):
             rc = self.lib.accbpg_fw_logdet_flush(self.h, C.byref(out))
@@ -71,11 +77,24 @@ class _FWState:
         return x, w, H
 
 
+def _drain(gen):
+    while True:
+        try:
+            next(gen)
+        except StopIteration as stop:
+            return stop.value
+
+
 def D_opt_FW(V, x0, eps, maxitrs, verbose=True, verbskip=1):
     """Frank-Wolfe with exact line search (accbpg/D_opt_alg.py:9-88).
     Returns (x, F, SP, SN, T).  F[k] = -log(detVXVT) with the determinant tracked by
     the rank-one formula (:52,:80); w is never refreshed; the stop test precedes the
     update so x matches F[-1] (:72).  ``V`` may be a matrix or a DOptimalObj."""
+    return _drain(D_opt_FW_steps(V, x0, eps, maxitrs, verbose, verbskip))
+
+
+def D_opt_FW_steps(V, x0, eps, maxitrs, verbose=True, verbskip=1):
+    """Generator form of D_opt_FW: yields k after each update, returns D_opt_FW's tuple."""
     start_time = time.time()
     st = _FWState(V, x0)
     m = st.m
@@ -111,17 +130,35 @@ def D_opt_FW(V, x0, eps, maxitrs, verbose=True, verbskip=1):
         coef = t / (1 + t * (w_i - 1))                          # :79,:82
         st.update(pr.i, 1 - t, t, -coef, 1 - t)                 # :76-79,:82
         detVXVT *= np.power(1 - t, m - 1) * (1 + t * (w_i - 1))  # :80
+        yield k
 
     return st.x(), F[0:k + 1], SP[0:k + 1], SN[0:k + 1], T[0:k + 1]
 
 
-def D_opt_FW_away(V, x0, eps, maxitrs, verbose=True, verbskip=1, logdet_refresh=1):
-    """Frank-Wolfe with Wolfe's away steps (accbpg/D_opt_alg.py:91-185).
-    Returns (x, F, SP, SN, T).  F[k] = log det(H) of the maintained inverse (:136).
+# How often D_opt_FW_away refactors the maintained inverse for F[k] = log det(H_k) when the caller does not say
+# (``logdet_refresh=None``).  See D_opt_FW_away.
+LOGDET_REFRESH_DEFAULT = 1
+LOGDET_RING_DEFAULT = 1
 
-    ``logdet_refresh`` (extension, default 1 = the reference's behaviour): refactor H
-    for log det every that many iterations; in between, log det(H) is advanced in
-    log-space by the matrix determinant lemma for the same rank-one update."""
+
+def D_opt_FW_away(V, x0, eps, maxitrs, verbose=True, verbskip=1, logdet_refresh=None, logdet_ring=None):
+    """Frank-Wolfe with Wolfe's away steps (accbpg/D_opt_alg.py:91-185).
+    Returns (x, F, SP, SN, T).  F[k] = log det(H_k) of the maintained inverse (:136), a logged value that no decision
+    of the iteration reads; iterates, gaps and step choices do not depend on how it is formed.
+
+    ``logdet_refresh`` (extension): 1 = the reference's computation, a fresh factorisation of H_k for every k (formed
+    beside the steps, ``logdet_ring`` of them in flight, F[k] filled in that many iterations late).  R > 1 = a fresh
+    factorisation of H_k for every k that is a multiple of R (beside the steps as well); in between log det(H) is
+    advanced in log space by the matrix determinant lemma for the very rank-one update the step applies,
+    log det(H+) = log det(H) + log(1 + c q) - m log(d) with q = v^T H v of the pivot column in the inverse as
+    maintained (computed on the device from H itself, not the tracked w), so the error of F[k] against a fresh
+    factorisation is the rounding of at most R - 1 such terms.  0 = never refactor (lemma from the start).
+    None = ``LOGDET_REFRESH_DEFAULT``."""
+    return _drain(D_opt_FW_away_steps(V, x0, eps, maxitrs, verbose, verbskip, logdet_refresh, logdet_ring))
+
+
+def D_opt_FW_away_steps(V, x0, eps, maxitrs, verbose=True, verbskip=1, logdet_refresh=None, logdet_ring=None):
+    """Generator form of D_opt_FW_away: yields k after each update, returns D_opt_FW_away's tuple."""
     start_time = time.time()
     st = _FWState(V, x0)
     m = st.m
@@ -129,47 +166,66 @@ def D_opt_FW_away(V, x0, eps, maxitrs, verbose=True, verbskip=1, logdet_refresh=
     SP = np.zeros(maxitrs)
     SN = np.zeros(maxitrs)
     T = np.zeros(maxitrs)
+    R = LOGDET_REFRESH_DEFAULT if logdet_refresh is None else int(logdet_refresh)
+    depth = LOGDET_RING_DEFAULT if logdet_ring is None else int(logdet_ring)
+    if R != 1:
+        depth = 1                                               # anchors are R iterations apart: one in flight is enough
+    st.logdet_ring(depth)
 
     if verbose:
         print("\nSolving D-opt design problem using Frank-Wolfe method with away steps")
         print("     k      F(x)     pos_slack   neg_slack    time")
 
-    # F[k] = log det(H_k) is only logged (no decision reads it), so with the reference's behaviour (a fresh
-    # factorisation every iteration) it is formed on a side stream while this loop already probes, decides and
-    # updates, and lands in F one iteration later -- same kernels, same numbers (accbpg_fw_probe_step, form 2);
-    # a table row is printed when its F value is in.
-    piped = (logdet_refresh == 1)
-    logdet_H = -st.logdet_gram
-    owed = None                                                 # iteration whose F (and table row) is still outstanding
+    # F[k] is filled in (and its table row printed) when its value is in: an anchor -- a fresh factorisation of H_a
+    # started at iteration a on a side stream -- arrives `depth` refreshing iterations later; the iterations between
+    # two anchors follow from the first by the log-space steps, each known one probe after its update (q_prev).
+    anchors = []            # iterations whose factorisation is in flight, oldest first
+    delta = np.zeros(maxitrs)   # delta[k] = log det(H_{k+1}) - log det(H_k) by the determinant lemma
+    filled = 0              # F[0:filled] is final
+    step = None             # (hcoef, hdiv) of the update applied at the previous iteration
 
-    def settle(value):
-        F[owed] = value
-        if verbose and owed % verbskip == 0:
-            print("{0:6d}  {1:10.3e}  {2:10.3e}  {3:10.3e}  {4:6.1f}".format(
-                owed, F[owed], SP[owed], SN[owed], T[owed]))
+    def fill(upto):
+        """F[filled:upto] from F[filled-1] by the log-space steps (upto exclusive), and print their rows."""
+        nonlocal filled
+        for j in range(filled, upto):
+            F[j] = F[j - 1] + delta[j - 1]
+            row(j)
+        filled = max(filled, upto)
+
+    def row(j):
+        if verbose and j % verbskip == 0:
+            print("{0:6d}  {1:10.3e}  {2:10.3e}  {3:10.3e}  {4:6.1f}".format(j, F[j], SP[j], SN[j], T[j]))
+
+    def settle(a, value):
+        """The anchor of iteration a is in."""
+        nonlocal filled
+        fill(a)
+        F[a] = value
+        row(a)
+        filled = a + 1
 
     k = -1
     for k in range(maxitrs):
-        refresh = (logdet_refresh > 0) and (k % logdet_refresh == 0)
-        pr = st.probe(away=1, refresh_logdet=(2 if piped else 1) if refresh else 0)   # :136, :145-147
-        if piped:
-            if owed is not None:
-                settle(pr.logdet_H)
-            owed = k
-        else:
-            if refresh:
-                logdet_H = pr.logdet_H
-            F[k] = logdet_H
+        refresh = (R > 0) and (k % R == 0)
+        pr = st.probe(away=1, refresh_logdet=2 if refresh else 0)   # :136, :145-147
         T[k] = time.time() - start_time
+        if step is not None:
+            hcoef, hdiv = step
+            delta[k - 1] = np.log1p(hcoef * pr.q_prev) - m * np.log(hdiv)
+        if refresh:
+            if len(anchors) >= depth:
+                settle(anchors.pop(0), pr.logdet_H)
+            anchors.append(k)
+        elif R == 0 and k == 0:
+            F[0] = -st.logdet_gram
+            filled = 1
         w_i, w_j = pr.w_i, pr.w_j
         eps_pos = w_i / m - 1                                   # :150
         eps_neg = 1 - w_j / m                                   # :151
         SP[k] = eps_pos
         SN[k] = eps_neg
-
-        if verbose and not piped and k % verbskip == 0:
-            print("{0:6d}  {1:10.3e}  {2:10.3e}  {3:10.3e}  {4:6.1f}".format(
-                k, F[k], eps_pos, eps_neg, T[k]))
+        if R == 0 and k == 0:
+            row(0)
 
         if eps_pos <= eps and eps_neg <= eps:                   # :159
             break
@@ -177,16 +233,17 @@ def D_opt_FW_away(V, x0, eps, maxitrs, verbose=True, verbskip=1, logdet_refresh=
         if eps_pos >= eps_neg:                                  # :162-170
             t = (w_i / m - 1) / (w_i - 1)
             coef = t / (1 - t + t * w_i)
+            step = (-coef, 1 - t)
             st.update(pr.i, 1 - t, t, -coef, 1 - t)
-            # det(H+) = det(H) * (1 - coef*w_i) / (1-t)^m
-            logdet_H += np.log1p(-coef * w_i) - m * np.log1p(-t)
         else:                                                   # :171-179
             x_j = pr.x_j
             t = min((1 - w_j / m) / (w_j - 1), x_j / (1 - x_j))
             coef = t / (1 + t - t * w_j)
+            step = (coef, 1 + t)
             st.update(pr.j, 1 + t, -t, coef, 1 + t)
-            logdet_H += np.log1p(coef * w_j) - m * np.log1p(t)
+        yield k
 
-    if piped and owed is not None:
-        settle(st.flush_logdet())
+    while anchors:
+        settle(anchors.pop(0), st.flush_logdet())
+    fill(k + 1)
     return st.x(), F[0:k + 1], SP[0:k + 1], SN[0:k + 1], T[0:k + 1]

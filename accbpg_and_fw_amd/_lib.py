@@ -21,7 +21,7 @@ _lib = None
 
 class FwProbe(C.Structure):
     _fields_ = [("i", C.c_int64), ("j", C.c_int64), ("w_i", C.c_double), ("w_j", C.c_double),
-                ("x_j", C.c_double), ("logdet_H", C.c_double)]
+                ("x_j", C.c_double), ("logdet_H", C.c_double), ("q_prev", C.c_double)]
 
 
 _P = C.c_void_p
@@ -81,6 +81,8 @@ _SIGS = {
     "accbpg_fw_init": (C.c_int, [_P, _P, C.POINTER(C.c_double)]),
     "accbpg_fw_probe_step": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FwProbe)]),
     "accbpg_fw_logdet_flush": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "accbpg_fw_logdet_ring": (C.c_int, [_P, C.c_int, C.c_int]),
+    "accbpg_fw_logdet_pending": (C.c_int, [_P]),
     "accbpg_fw_update": (C.c_int, [_P, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double]),
     "accbpg_fw_get_state": (C.c_int, [_P, _P, _P, _P]),
     "accbpg_poisson_create": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, _P, _P, C.POINTER(_P)]),

@@ -91,12 +91,12 @@ extern "C" int accbpg_dopt_destroy(accbpg_dopt* h) {
     hipFree(h->chol_jobs); hipFree(h->chol_ready); hipFree(h->chol_aux); hipFree(h->chol_hand); hipFree(h->Gbuf);
     if (h->hpin) hipHostFree(h->hpin);
     if (h->ev_done) hipEventDestroy(h->ev_done);
-    if (h->fw_side) { hipStreamSynchronize(h->fw_side); hipStreamDestroy(h->fw_side); }
-    if (h->fw_ev_h) hipEventDestroy(h->fw_ev_h);
-    if (h->fw_ev_snap) hipEventDestroy(h->fw_ev_snap);
-    if (h->fw_ev_chol) hipEventDestroy(h->fw_ev_chol);
-    hipFree(h->fw_sd);
-    if (h->fw_sp) hipHostFree(h->fw_sp);
+    for (auto& sl : h->fw_ring) {
+        if (sl.stream) hipStreamSynchronize(sl.stream);
+        if (sl.aux) accbpg_dopt_destroy(sl.aux);
+        if (sl.stream) hipStreamDestroy(sl.stream);
+        if (sl.ev_snap) hipEventDestroy(sl.ev_snap);
+    }
     for (auto& p : h->prof)
         for (auto e : p.ev) hipEventDestroy(e);
     delete h;

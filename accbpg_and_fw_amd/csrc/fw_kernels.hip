@@ -182,8 +182,27 @@ __global__ __launch_bounds__(FB) void fw_gemv_h_kernel(const double* __restrict_
 }
 
 // H <- (H + hcoef*outer(hv,hv)) / hdiv       (D_opt_alg.py:79,167,176); a row per workgroup pass
+// Workgroup 0 also leaves q = v_p^T (H v_p), the quadratic form of the pivot column in the inverse AS MAINTAINED (the
+// tracked w_p drifts away from it: w is never refreshed, D_opt_alg.py:82): by the matrix determinant lemma
+// det(H+) = det(H) (1 + hcoef q) / hdiv^m holds for exactly this q, which is what the log-space advance of log det(H)
+// between two factorisations uses (accbpg_fw_probe: q_prev).
 __global__ __launch_bounds__(FB) void fw_rank1_kernel(double* __restrict__ H, int64_t m,
-                                                     const double* __restrict__ hv, double hcoef, double hdiv) {
+                                                     const double* __restrict__ hv, double hcoef, double hdiv,
+                                                     const double* __restrict__ vp, double* __restrict__ qout) {
+    if (blockIdx.x == 0) {
+        __shared__ double qs[FB / 64];
+        double q = 0.0;
+        for (int64_t c = threadIdx.x; c < m; c += FB) q = fma(vp[c], hv[c], q);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off);
+        if ((threadIdx.x & 63) == 0) qs[threadIdx.x >> 6] = q;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = qs[0];
+            for (int i = 1; i < FB / 64; ++i) t += qs[i];
+            *qout = t;
+        }
+    }
     for (int64_t r = blockIdx.x; r < m; r += gridDim.x) {
         const double hr = hv[r];
         double* row = H + r * m;
@@ -348,10 +367,11 @@ static int read_scalars(accbpg_dopt* h, int nd, int ni) {
     return ACCBPG_OK;
 }
 
-static int fw_side_collect(accbpg_dopt* h, double* logdet);
+static int fw_ring_drain(accbpg_dopt* h);
 
 extern "C" int accbpg_fw_init(accbpg_dopt* h, const double* x0_dev, double* logdet_gram_host) {
     if (!h || !x0_dev) return ACCBPG_ERR_ARG;
+    ACC_TRY(fw_ring_drain(h));                                 // factorisations left in flight by an earlier run
     ACC_TRY(fw_alloc(h));
     const int64_t m = h->m;
     ACC_TRY(device_copy(h->fw_x, x0_dev, (size_t)h->n, h->stream));
@@ -380,86 +400,119 @@ extern "C" int accbpg_fw_init(accbpg_dopt* h, const double* x0_dev, double* logd
     ACC_HIP(hipMemcpyAsync(h->chol_op, &op, sizeof(GemmOp), hipMemcpyHostToDevice, h->stream));
     ACC_TRY(launch_gemm_ops(h->chol_op, 1, (int)m, (int)m, true, h->stream));
     mirror_lower_kernel<<<1024, FB, 0, h->stream>>>(h->fw_H, m);
+    ACC_HIP(hipMemsetAsync(h->dscal + 10, 0, sizeof(double), h->stream));   // q of "the previous update": none yet
     ACC_HIP(hipGetLastError());
     ACC_HIP(hipStreamSynchronize(h->stream));
     h->fw_ready = true;
     h->fw_part_nblk = 0;
-    if (h->fw_pipe_pending) {                                   // a factorisation left over from an earlier run
-        double unused;
-        ACC_TRY(fw_side_collect(h, &unused));
-    }
-    h->fw_snap_pending = false;
     return ACCBPG_OK;
 }
 
-// ---- log det(H) one iteration behind (refresh_logdet = 2) ------------------------------------------------------
+// ---- log det(H) beside the steps (refresh_logdet = 2) ----------------------------------------------------------
 // F[k] = log det(H_k) of the away-step variant (D_opt_alg.py:136) is a LOGGED value: no decision of the iteration
-// reads it.  So its O(m^3) factorisation need not sit between two HBM-bound steps: a snapshot of H_k is taken on a
-// side stream and factored there while the main stream probes, decides and applies update k; the value is collected
-// by the next call (or by accbpg_fw_logdet_flush).  Same kernels on the same matrix: the numbers are those of the
-// synchronous form.
-static int fw_side_setup(accbpg_dopt* h) {
-    if (h->fw_side) return ACCBPG_OK;
-    ACC_HIP(hipStreamCreateWithFlags(&h->fw_side, hipStreamNonBlocking));
-    ACC_HIP(hipEventCreateWithFlags(&h->fw_ev_h, hipEventDisableTiming));
-    ACC_HIP(hipEventCreateWithFlags(&h->fw_ev_snap, hipEventDisableTiming));
-    ACC_HIP(hipEventCreateWithFlags(&h->fw_ev_chol, hipEventDisableTiming));
-    ACC_HIP(hipMalloc(&h->fw_sd, sizeof(double) * 24));
-    ACC_HIP(hipMemset(h->fw_sd, 0, sizeof(double) * 24));
-    ACC_HIP(hipHostMalloc(&h->fw_sp, sizeof(double) * 24, hipHostMallocDefault));
-    return ACCBPG_OK;
-}
-
-// factor the snapshot on the side stream with the side scalars (the main stream's probe keeps its own)
-static int fw_side_factor(accbpg_dopt* h, double* snap) {
-    hipStream_t s0 = h->stream;
-    double* d0 = h->dscal;
-    int* f0 = h->dflag;
-    h->stream = h->fw_side; h->dscal = h->fw_sd; h->dflag = reinterpret_cast<int*>(h->fw_sd + 16);
-    const int rc = launch_cholesky(h, h->Lbuf, nullptr, nullptr, snap);
-    h->stream = s0; h->dscal = d0; h->dflag = f0;
-    ACC_TRY(rc);
-    ACC_HIP(hipMemcpyAsync(h->fw_sp, h->fw_sd, sizeof(double) * STATUS_DOUBLES, hipMemcpyDeviceToHost, h->fw_side));
-    ACC_HIP(hipEventRecord(h->fw_ev_chol, h->fw_side));
-    return ACCBPG_OK;
-}
-
-// wait for the side factorisation in flight and return its log det (NaN if the matrix was not positive definite)
-static int fw_side_collect(accbpg_dopt* h, double* logdet) {
-    *logdet = __builtin_nan("");
-    if (!h->fw_pipe_pending) return ACCBPG_OK;
-    ACC_HIP(hipEventSynchronize(h->fw_ev_chol));
-    const int* fl = reinterpret_cast<const int*>(h->fw_sp + 16);
-    if (fl[FLAG_ABORT] && !h->chol_tiles_off) {
-        // the one-launch factorisation gave up a wait: the snapshot is intact, factor it with a launch per block column
-        h->chol_tiles_off = true;
-        ACC_TRY(fw_side_factor(h, h->Gbuf ? h->Gbuf : h->Lbuf));
-        ACC_HIP(hipEventSynchronize(h->fw_ev_chol));
+// reads it.  So its O(m^3) factorisation need not sit between two HBM-bound steps: H_k is copied into a slot of a ring
+// (one copy kernel on the main stream, in order with the updates) and factored on that slot's own stream by that
+// slot's own auxiliary handle -- own buffers, own hand-off flags, own scalars -- while the main stream probes, decides
+// and applies the updates that follow; the value is collected when the slot comes round again, `depth` such calls
+// later (or by accbpg_fw_logdet_flush).  Same kernels on the same matrix as the synchronous form (refresh_logdet =
+// 1): the numbers are those.  Nothing of the slots is shared with the main handle, so an evaluation on the main
+// handle while factorisations are in flight is safe.
+static int fw_ring_setup(accbpg_dopt* h) {
+    while ((int)h->fw_ring.size() < h->fw_ring_depth) {
+        accbpg_dopt::FwSlot sl;
+        ACC_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        ACC_HIP(hipEventCreateWithFlags(&sl.ev_snap, hipEventDisableTiming));
+        const int rc = accbpg_dopt_create(h->V, h->m, h->n, h->ldv, sl.stream, &sl.aux, 1);
+        if (rc != ACCBPG_OK) {
+            hipStreamDestroy(sl.stream);
+            hipEventDestroy(sl.ev_snap);
+            return rc;
+        }
+        h->fw_ring.push_back(sl);
     }
-    h->fw_pipe_pending = false;
-    if (!fl[FLAG_NOT_PD]) *logdet = h->fw_sp[0];
     return ACCBPG_OK;
 }
 
+static int fw_slot_factor(accbpg_dopt::FwSlot& sl, const double* snap) {
+    accbpg_dopt* a = sl.aux;
+    ACC_TRY(launch_cholesky(a, a->Lbuf, nullptr, nullptr, snap));
+    ACC_HIP(hipMemcpyAsync(a->hpin, a->dscal, sizeof(double) * STATUS_DOUBLES, hipMemcpyDeviceToHost, a->stream));
+    ACC_HIP(hipEventRecord(a->ev_done, a->stream));
+    return ACCBPG_OK;
+}
+
+// wait for the slot's factorisation and return its log det (NaN if the matrix was not positive definite)
+static int fw_slot_collect(accbpg_dopt::FwSlot& sl, double* logdet) {
+    *logdet = __builtin_nan("");
+    if (!sl.pending) return ACCBPG_OK;
+    accbpg_dopt* a = sl.aux;
+    ACC_HIP(hipEventSynchronize(a->ev_done));
+    const int* fl = reinterpret_cast<const int*>(a->hpin + 16);
+    if (fl[FLAG_ABORT] && !a->chol_tiles_off) {
+        // the one-launch factorisation gave up a wait: the snapshot (in Gbuf) is intact, factor it with a launch per
+        // block column, and keep this slot on those
+        a->chol_tiles_off = true;
+        ACC_TRY(fw_slot_factor(sl, a->Gbuf));
+        ACC_HIP(hipEventSynchronize(a->ev_done));
+    }
+    sl.pending = false;
+    if (!fl[FLAG_NOT_PD]) *logdet = a->hpin[0];
+    return ACCBPG_OK;
+}
+
+static int fw_ring_drain(accbpg_dopt* h) {
+    for (auto& sl : h->fw_ring) {
+        double unused;
+        ACC_TRY(fw_slot_collect(sl, &unused));
+    }
+    h->fw_ring_collected = h->fw_ring_issued;
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_fw_logdet_ring(accbpg_dopt* h, int depth, int small_launches) {
+    if (!h || depth < 1 || depth > 16 || small_launches < 0 || small_launches > 2) return ACCBPG_ERR_ARG;
+    ACC_TRY(fw_ring_drain(h));
+    h->fw_ring_depth = depth;
+    h->fw_ring_small = small_launches;
+    for (auto& sl : h->fw_ring) sl.aux->chol_tiles_off = false;   // (a slot that had to give up the one launch finds out again)
+    h->fw_ring_issued = h->fw_ring_collected = 0;              // slot = issue count modulo depth
+    return ACCBPG_OK;
+}
+
+extern "C" int accbpg_fw_logdet_pending(accbpg_dopt* h) {
+    return h ? (int)(h->fw_ring_issued - h->fw_ring_collected) : 0;
+}
+
+// the oldest factorisation in flight (NaN when there is none)
 extern "C" int accbpg_fw_logdet_flush(accbpg_dopt* h, double* logdet_host) {
     if (!h || !logdet_host) return ACCBPG_ERR_ARG;
-    return fw_side_collect(h, logdet_host);
+    *logdet_host = __builtin_nan("");
+    if (h->fw_ring_collected >= h->fw_ring_issued) return ACCBPG_OK;
+    accbpg_dopt::FwSlot& sl = h->fw_ring[(size_t)(h->fw_ring_collected % h->fw_ring_depth)];
+    ACC_TRY(fw_slot_collect(sl, logdet_host));
+    ++h->fw_ring_collected;
+    return ACCBPG_OK;
 }
 
 extern "C" int accbpg_fw_probe_step(accbpg_dopt* h, int away, int refresh_logdet, accbpg_fw_probe* out) {
     if (!h || !out || !h->fw_ready) return ACCBPG_ERR_ARG;
-    double logdet = 0.0;
+    double logdet = __builtin_nan("");
     if (refresh_logdet == 2) {
-        ACC_TRY(fw_side_setup(h));
-        ACC_TRY(fw_side_collect(h, &logdet));                   // the PREVIOUS step's log det(H) (NaN on the first call)
-        double* snap = h->Gbuf ? h->Gbuf : h->Lbuf;
-        ACC_HIP(hipEventRecord(h->fw_ev_h, h->stream));         // H_k is complete behind everything queued so far
-        ACC_HIP(hipStreamWaitEvent(h->fw_side, h->fw_ev_h, 0));
-        ACC_TRY(device_copy(snap, h->fw_H, (size_t)h->m * h->m, h->fw_side));
-        ACC_HIP(hipEventRecord(h->fw_ev_snap, h->fw_side));     // from here on H may change
-        ACC_TRY(fw_side_factor(h, snap));
-        h->fw_pipe_pending = true;
-        h->fw_snap_pending = true;
+        ACC_TRY(fw_ring_setup(h));
+        // the slot that comes round: collect what it holds -- the value of the call made `depth` such calls ago
+        if (h->fw_ring_issued - h->fw_ring_collected >= h->fw_ring_depth) ACC_TRY(accbpg_fw_logdet_flush(h, &logdet));
+        accbpg_dopt::FwSlot& sl = h->fw_ring[(size_t)(h->fw_ring_issued % h->fw_ring_depth)];
+        accbpg_dopt* a = sl.aux;
+        const int64_t T = (h->m + NB - 1) / NB;
+        if (!a->chol_tiles_off)
+            a->chol_tiles_off = h->fw_ring_small == 1 || (h->fw_ring_small == 2 && T * (T + 1) / 2 >= h->num_cu);
+        double* snap = chol_tiles_usable(a) ? a->Gbuf : a->Lbuf;
+        ACC_TRY(device_copy(snap, h->fw_H, (size_t)h->m * h->m, h->stream));   // H_k, in order with the updates
+        ACC_HIP(hipEventRecord(sl.ev_snap, h->stream));
+        ACC_HIP(hipStreamWaitEvent(sl.stream, sl.ev_snap, 0));
+        ACC_TRY(fw_slot_factor(sl, snap));
+        sl.pending = true;
+        ++h->fw_ring_issued;
     } else if (refresh_logdet) {
         // F[k] = log det(H) from a fresh factorisation of the maintained inverse (D_opt_alg.py:136)
         // (the factor goes to Lbuf; H itself is read in place by the one-launch kernel, copied otherwise)
@@ -497,6 +550,7 @@ extern "C" int accbpg_fw_probe_step(accbpg_dopt* h, int away, int refresh_logdet
     out->w_j = h->hpin[5];
     out->x_j = h->hpin[6];
     out->logdet_H = logdet;
+    out->q_prev = h->hpin[10];
     return ACCBPG_OK;
 }
 
@@ -507,10 +561,6 @@ extern "C" int accbpg_fw_update(accbpg_dopt* h, int64_t p, double xscale, double
         return ACCBPG_ERR_ARG;
     }
     const int64_t m = h->m, n = h->n;
-    if (h->fw_snap_pending) {                                   // the side stream's snapshot of H comes before this update
-        ACC_HIP(hipStreamWaitEvent(h->stream, h->fw_ev_snap, 0));
-        h->fw_snap_pending = false;
-    }
     double* vp = h->fw_hv + m;
     int64_t gb = (std::max(n, m) + FB - 1) / FB;
     if (gb > 1024) gb = 1024;
@@ -519,7 +569,7 @@ extern "C" int accbpg_fw_update(accbpg_dopt* h, int64_t p, double xscale, double
     fw_gemv_h_kernel<<<(int)((pairs + FB / 64 - 1) / (FB / 64)), FB, 0, h->stream>>>(h->fw_H, m, vp, h->fw_hv);
     int64_t rb = m;
     if (rb > 4096) rb = 4096;
-    fw_rank1_kernel<<<(int)rb, FB, 0, h->stream>>>(h->fw_H, m, h->fw_hv, hcoef, hdiv);
+    fw_rank1_kernel<<<(int)rb, FB, 0, h->stream>>>(h->fw_H, m, h->fw_hv, hcoef, hdiv, vp, h->dscal + 10);
     const int ns = fw_nsplit(h);
     dim3 vg((unsigned)((n + VG_COLS - 1) / VG_COLS), (unsigned)ns);
     fw_vgemv_partial_kernel<<<vg, FB, 0, h->stream>>>(h->V, h->ldv, m, n, h->fw_hv, ns, h->vws, h->vec_ok);

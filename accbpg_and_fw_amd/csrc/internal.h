@@ -151,13 +151,19 @@ struct accbpg_dopt {
     // Frank-Wolfe state
     double *fw_x = nullptr, *fw_w = nullptr, *fw_H = nullptr, *fw_hv = nullptr;
     bool fw_ready = false;
-    // log det(H) of the away-step variant factored on a side stream, one iteration behind the step it belongs to
-    hipStream_t fw_side = nullptr;
-    hipEvent_t fw_ev_h = nullptr, fw_ev_snap = nullptr, fw_ev_chol = nullptr;
-    double* fw_sd = nullptr;        // device scalars + flags of the side factorisation (24 doubles)
-    double* fw_sp = nullptr;        // pinned mirror
-    bool fw_pipe_pending = false;   // a side factorisation is in flight
-    bool fw_snap_pending = false;   // ... and its snapshot of H may not have been taken yet
+    // log det(H) of the away-step variant (D_opt_alg.py:136) factored beside the steps: a ring of snapshot slots, each an
+    // auxiliary handle (own buffers, own stream) that factors a copy of H_k while the main stream goes on
+    struct FwSlot {
+        accbpg_dopt* aux = nullptr;     // owns snapshot / factor buffers, scalars, pinned mirror, ev_done
+        hipStream_t stream = nullptr;   // created here
+        hipEvent_t ev_snap = nullptr;   // recorded on the main stream behind the snapshot copy
+        bool pending = false;
+    };
+    std::vector<FwSlot> fw_ring;
+    int fw_ring_depth = 1;          // slots in use (factorisations in flight)
+    int fw_ring_small = 2;          // how the slots factor: 0 one launch, 1 a launch per block column, 2 by size (as
+                                    // accbpg_dopt_factor_in_small_launches)
+    long long fw_ring_issued = 0, fw_ring_collected = 0;
     int fw_part_nblk = 0;       // probe stage-1 records left behind by the last w update (0: none)
     bool fw_part_away = false;  // support threshold they were computed for
 

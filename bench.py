@@ -87,6 +87,11 @@ def parse(argv=None):
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the variant segments (profiling runs: the kernel trace then holds the headline "
                          "and steady-state regions only)")
+    ap.add_argument("--logdet-refresh", type=int, default=None,
+                    help="fw_away: refactor H for F[k] = log det(H_k) every this many iterations (1 = every iteration, "
+                         "the reference's computation; default: the package's, D_opt_alg.LOGDET_REFRESH_DEFAULT)")
+    ap.add_argument("--logdet-ring", type=int, default=None,
+                    help="fw_away with --logdet-refresh 1: factorisations in flight beside the steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--launch-check", action="store_true",
@@ -133,28 +138,13 @@ def make_instance(m, n, seed, device):
     return torch.from_numpy(V).to(device)
 
 
-class FWStepper:
-    """Frank-Wolfe loops as step generators over the same entry points D_opt_FW* use."""
-
-    def __init__(self, acc, f, x0, away, maxitrs):
-        from accbpg_and_fw_amd.D_opt_alg import _FWState
-        self.st = _FWState(f, x0)
-        self.away = away
-        self.m = f.m
-
-    def step(self):
-        st, m = self.st, self.m
-        pr = st.probe(away=1 if self.away else 0, refresh_logdet=2 if self.away else 0)   # F[k] one iteration behind, as D_opt_FW_away
-        w_i, w_j = pr.w_i, pr.w_j
-        eps_pos, eps_neg = w_i / m - 1, 1 - w_j / m
-        if (not self.away) or eps_pos >= eps_neg:
-            t = (w_i / m - 1) / (w_i - 1)
-            coef = t / (1 - t + t * w_i) if self.away else t / (1 + t * (w_i - 1))
-            st.update(pr.i, 1 - t, t, -coef, 1 - t)
-        else:
-            t = min((1 - w_j / m) / (w_j - 1), pr.x_j / (1 - pr.x_j))
-            coef = t / (1 + t - t * w_j)
-            st.update(pr.j, 1 + t, -t, coef, 1 + t)
+def fw_generator(f, x0, away, maxitrs, logdet_refresh, logdet_ring):
+    """The package's own Frank-Wolfe loops as step generators (accbpg_and_fw_amd/D_opt_alg.py); eps < 0: never stops."""
+    from accbpg_and_fw_amd.D_opt_alg import D_opt_FW_away_steps, D_opt_FW_steps
+    if away:
+        return D_opt_FW_away_steps(f, x0, -1.0, maxitrs, verbose=False, logdet_refresh=logdet_refresh,
+                                   logdet_ring=logdet_ring)
+    return D_opt_FW_steps(f, x0, -1.0, maxitrs, verbose=False)
 
 
 # ---- SURVEY 8(f) row 4: Poisson linear inverse problem (HBM-bound objective), single GPU
@@ -382,11 +372,11 @@ def main():
             for _ in range(count):
                 next(gen)
     else:
-        fw = FWStepper(acc, f, x0, args.workload == "fw_away", total + 1)
+        gen = fw_generator(f, x0, args.workload == "fw_away", total + 1, args.logdet_refresh, args.logdet_ring)
 
         def advance(count=1):
             for _ in range(count):
-                fw.step()
+                next(gen)
 
     def barrier():
         torch.cuda.synchronize()

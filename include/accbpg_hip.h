@@ -235,6 +235,8 @@ typedef struct accbpg_fw_probe {
     double  w_j;       /* w[j] (FW: min of w over x > 0)                                       */
     double  x_j;       /* x[j]                                                                */
     double  logdet_H;  /* log det of the maintained inverse H  (D_opt_alg.py:136)              */
+    double  q_prev;    /* v_p^T H v_p of the LAST accbpg_fw_update's pivot column p in the inverse as it stood before
+                          that update (0 before the first): det(H+) = det(H) (1 + hcoef q) / hdiv^m             */
 } accbpg_fw_probe;
 
 /* x <- x0; H <- (V diag(x0) V^T)^-1; w <- diag(V^T H V)   (D_opt_alg.py:39-45 / 123-129).
@@ -247,9 +249,16 @@ int accbpg_fw_init(accbpg_dopt* h, const double* x0_dev, double* logdet_gram_hos
 int accbpg_fw_probe_step(accbpg_dopt* h, int away, int refresh_logdet, accbpg_fw_probe* probe_host);
 
 /* refresh_logdet = 2 is the pipelined form of 1: log det(H) is a logged value that no decision of the iteration reads
- * (D_opt_alg.py:136 -> F[k] only), so a snapshot of the current H is factored on a side stream while the caller goes on
- * to probe, decide and update; probe_host->logdet_H then holds the value that belongs to the PREVIOUS call made this way
- * (NaN on the first), and accbpg_fw_logdet_flush collects the last one.  Same kernels on the same matrices as form 1. */
+ * (D_opt_alg.py:136 -> F[k] only), so a copy of the current H is factored on a side stream (by an auxiliary handle with
+ * buffers of its own) while the caller goes on to probe, decide and update.  `depth` such factorisations may be in
+ * flight (accbpg_fw_logdet_ring; default 1): probe_host->logdet_H holds the value that belongs to the call made this way
+ * `depth` calls earlier (NaN while there is none), accbpg_fw_logdet_flush collects the oldest one still in flight (NaN
+ * when none is), accbpg_fw_logdet_pending counts them.  Same kernels on the same matrices as form 1.
+ * small_launches: how the side factorisations run, as accbpg_dopt_factor_in_small_launches (0 one launch, 1 a launch
+ * per block column, 2 by size).  A caller that refreshes only every R-th call and advances log det(H) in between by
+ * the matrix determinant lemma uses q_prev (D_opt_FW_away(..., logdet_refresh=R) of the Python package). */
+int accbpg_fw_logdet_ring(accbpg_dopt* h, int depth, int small_launches);
+int accbpg_fw_logdet_pending(accbpg_dopt* h);
 int accbpg_fw_logdet_flush(accbpg_dopt* h, double* logdet_host);
 
 /* One rank-one update with pivot column p (i for a Frank-Wolfe step, j for an away step):

@@ -311,6 +311,28 @@ def large_bpg_long(accbpg, m=2048, n=32768, seed=10, iters=300):
     save("large_bpg_long", m=m, n=n, seed=seed, iters=iters, x=x, F=F, Ls=Ls, ref_seconds=T[-1])
 
 
+def m8192(accbpg, m=8192, n=16400, seed=10, iters=3):
+    """Config-5's m (two-level Cholesky, the replicated tail of the sharded evaluation) against the real
+    reference: per-call values at two points and a few ABPG iterations.  n is ragged on purpose (16400 =
+    128*128 + 16: the last column tile of the gradient product is partial, and 8 logical shards are unequal)."""
+    import numpy as np
+    import time
+    f, h, L, x0 = accbpg.D_opt_design(m, n, randseed=seed)
+    t = time.time()
+    f0, g0 = f.func_grad(x0, 2)
+    print("func_grad at x0: %.1f s" % (time.time() - t), flush=True)
+    rng = np.random.RandomState(8192)
+    x = rng.rand(n) + 0.05
+    x /= x.sum()
+    fx, g = f.func_grad(x, 2)
+    out = {"m": m, "n": n, "seed": seed, "iters": iters, "f0": f0, "g0": g0, "x": x, "f": fx, "g": g}
+    t = time.time()
+    xs, F, G, T = accbpg.ABPG(f, h, L, x0, gamma=2, maxitrs=iters, theta_eq=True, verbose=False)
+    print("ABPG %d its: %.1f s" % (iters, time.time() - t), flush=True)
+    out.update(abpg_x=xs, abpg_F=F, abpg_G=G)
+    save("percall_%dx%d" % (m, n), **out)
+
+
 def traces_512(accbpg):
     """1000-iteration traces at the config-4 instance size (about 10 minutes of CPU)."""
     f, h, L, x0 = accbpg.D_opt_design(512, 8192, randseed=10)
@@ -436,6 +458,7 @@ def main():
     ap.add_argument("--only-large-abpg-1000", action="store_true")
     ap.add_argument("--only-large-fw-long", action="store_true")
     ap.add_argument("--only-large-bpg-long", action="store_true")
+    ap.add_argument("--only-m8192", action="store_true")
     ap.add_argument("--keep", default="16,24,32,40,48,56", help="iterations whose iterate the long ABPG_gain fixture keeps")
     ap.add_argument("--name", default="large_gain_long")
     ap.add_argument("--m", type=int, default=2048)
@@ -449,6 +472,9 @@ def main():
         OUT = args.out
     if args.only_poisson:
         poisson(accbpg)
+        return
+    if args.only_m8192:
+        m8192(accbpg)
         return
     if args.only_large_long:
         large_long(accbpg)

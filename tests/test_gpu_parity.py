@@ -456,14 +456,69 @@ def test_large_abpg_gain_trajectory_2048x32768(large, acc):
     _close(F, gd["F"], 1e-9); _close(Gain, gd["Gain"], 1e-12); _close(Gdiv, gd["Gdiv"], 1e-7)
 
 
-def test_large_abpg_gain_past_first_retries_2048x32768(large, acc):
+class _LoggedObjective:
+    """Pass-through over a DOptimalObj that notes kind, returned value and (at the call positions in `tap_positions`)
+    the argument of every oracle call, in the order the reference's loop makes them (the way oracle/gen_golden.py's
+    _CallLog notes the reference's).  overlap=False puts F[k] = f(x) on the solver's stream; overlap=True is the
+    package default: the solvers start F[k] through value_async on the objective's second handle and stream (whose
+    factorisation runs in small launches for m > 1408) beside func_grad(y) and collect it through value_wait -- the
+    value is logged at the position of the call that started it, which is where the reference evaluates it."""
+
+    def __init__(self, f, overlap, tap_positions=()):
+        self.f = f
+        self.m, self.n, self.H = f.m, f.n, f.H
+        self.device = f.device
+        self._overlap = bool(overlap)
+        self._lin = False
+        self.kinds, self.values, self.taps = [], [], {}
+        self.async_values = 0
+        self.tap_positions = set(int(p) for p in tap_positions)
+
+    def _note(self, x):
+        if len(self.kinds) in self.tap_positions:
+            self.taps[len(self.kinds)] = x.detach().clone()
+
+    def __call__(self, x):
+        self._note(x)
+        v = self.f.func_grad(x, 0)
+        self.kinds.append(0); self.values.append(v)
+        return v
+
+    def value_async(self, x):
+        self._note(x)
+        self.kinds.append(0); self.values.append(float("nan"))
+        self.async_values += 1
+        return (len(self.values) - 1, self.f.value_async(x))
+
+    def value_wait(self, ticket):
+        pos, inner = ticket
+        v = self.f.value_wait(inner)
+        self.values[pos] = v
+        return v
+
+    def value_lead_seconds(self):
+        return self.f.value_lead_seconds()
+
+    def func_grad(self, x, flag=2):
+        self._note(x)
+        out = self.f.func_grad(x, flag)
+        self.kinds.append(flag); self.values.append(out[0] if flag == 2 else float("nan"))
+        return out
+
+    def gradient(self, x):
+        return self.func_grad(x, 1)
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_large_abpg_gain_past_first_retries_2048x32768(large, acc, overlap):
     """The headline solver at the headline size through the first line-search retries: 64 iterations of
     ABPG_gain(gamma=2) at D_opt_design(2048,32768) against the trace of the real reference
     (oracle/gen_golden.py --only-large-gain-long; accbpg/algorithms.py:361-390).  The fixture holds the
     gain sequence, the value EVERY oracle call returned in call order (rejected trial points included), and
     iterates x_k along the run.  Required: the same accept/reject decisions (identical gain sequence and call
     pattern), every F[k] to 1e-9 (every evaluated objective value, rejected trial points too, to 1e-7),
-    l_inf(x_k) < 1e-9 at the stored iterates."""
+    l_inf(x_k) < 1e-9 at the stored iterates.  Run on both evaluation paths: F[k] on the solver's stream, and the package
+    default (F[k] on the second handle and stream beside func_grad(y), its factorisation in small launches)."""
     import os
     if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "large_gain_long.npz")):
         pytest.skip("tests/golden/large_gain_long.npz not generated")
@@ -474,33 +529,11 @@ def test_large_abpg_gain_past_first_retries_2048x32768(large, acc):
     retries = np.flatnonzero(ref_gain[1:] > ref_gain[:-1] / 1.2 * (1 + 1e-12)) + 1
     assert retries.size >= 10, "fixture must contain line-search retries"     # the regime the solver lives in
 
-    kinds, values, iterates = [], [], {}
     keep = set(int(k) for k in gd["keep"])
-    inner_value, inner_fg = f.__call__, f.func_grad
-
-    class Logged:
-        """Pass-through that notes kind and returned value of every oracle call, like the generator's."""
-        m, n, H = f.m, f.n, f.H
-        device = f.device
-        _overlap = False                                        # calls then arrive in the reference's order
-        _lin = False
-
-        def __call__(self, x):
-            v = inner_fg(x, 0)
-            kinds.append(0); values.append(v)
-            return v
-
-        def func_grad(self, x, flag=2):
-            out = inner_fg(x, flag)
-            kinds.append(flag); values.append(out[0] if flag == 2 else float("nan"))
-            return out
-
-        def gradient(self, x):
-            return self.func_grad(x, 1)
-
     from accbpg_and_fw_amd.algorithms import ABPG_gain_steps
     xd = torch.from_numpy(x0).cuda()
-    gen = ABPG_gain_steps(Logged(), h, L, xd, 2, iters, verbose=False)
+    logged = _LoggedObjective(f, overlap)
+    gen = ABPG_gain_steps(logged, h, L, xd, 2, iters, verbose=False)
     result = None
     while True:
         try:
@@ -508,6 +541,8 @@ def test_large_abpg_gain_past_first_retries_2048x32768(large, acc):
         except StopIteration as stop:
             result = stop.value
             break
+    kinds, values = logged.kinds, logged.values
+    assert logged.async_values == (iters if overlap else 0)     # overlap=True really ran F[k] on the side handle
     x, F, Gain, Gdiv, Gavg, T = result
     assert len(F) == iters
     np.testing.assert_array_equal(np.array(kinds, dtype=np.int8), gd["call_kinds"])     # same call pattern
@@ -534,44 +569,22 @@ def test_large_abpg_gain_past_first_retries_2048x32768(large, acc):
     assert 1.7 <= np.sum(kk == 2) / 20 <= 2.3 and 2.6 <= np.sum(kk == 0) / 20 <= 3.4
 
 
-def _logged_gain_run(f, h, L, x0, iters, tap_positions=()):
+def _logged_gain_run(f, h, L, x0, iters, tap_positions=(), overlap=False):
     """ABPG_gain(gamma=2) with kind, returned value and (at the call positions in `tap_positions`) the argument of
-    every oracle call noted, the way oracle/gen_golden.py's _CallLog notes the reference's."""
-    kinds, values, taps = [], [], {}
-    inner_fg = f.func_grad
-    tap_positions = set(int(p) for p in tap_positions)
-
-    class Logged:
-        m, n, H = f.m, f.n, f.H
-        device = f.device
-        _overlap = False                                        # calls then arrive in the reference's order
-        _lin = False
-
-        def __call__(self, x):
-            if len(kinds) in tap_positions:
-                taps[len(kinds)] = x.detach().clone()
-            v = inner_fg(x, 0)
-            kinds.append(0); values.append(v)
-            return v
-
-        def func_grad(self, x, flag=2):
-            out = inner_fg(x, flag)
-            kinds.append(flag); values.append(out[0] if flag == 2 else float("nan"))
-            return out
-
-        def gradient(self, x):
-            return self.func_grad(x, 1)
-
+    every oracle call noted (_LoggedObjective)."""
+    logged = _LoggedObjective(f, overlap, tap_positions)
     from accbpg_and_fw_amd.algorithms import ABPG_gain_steps
-    gen = ABPG_gain_steps(Logged(), h, L, torch.from_numpy(x0).cuda(), 2, iters, verbose=False)
+    gen = ABPG_gain_steps(logged, h, L, torch.from_numpy(x0).cuda(), 2, iters, verbose=False)
     while True:
         try:
             next(gen)
         except StopIteration as stop:
-            return stop.value, np.array(kinds, dtype=np.int8), np.array(values), taps
+            assert logged.async_values == (iters if overlap else 0)
+            return stop.value, np.array(logged.kinds, dtype=np.int8), np.array(logged.values), logged.taps
 
 
-def test_large_abpg_gain_300_iterations_2048x32768(large, acc):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_large_abpg_gain_300_iterations_2048x32768(large, acc, overlap):
     """The headline solver at the headline size deep into the regime it lives in: 300 iterations of ABPG_gain(gamma=2)
     at D_opt_design(2048,32768) against the call log of the real reference (oracle/gen_golden.py
     --only-large-gain-long --iters 300 --name large_gain_300; 2.1 hours of CPU; accbpg/algorithms.py:295-420): 1458
@@ -600,7 +613,7 @@ def test_large_abpg_gain_300_iterations_2048x32768(large, acc):
     ref_gain = gd["Gain"]
     ref_kinds, ref_values = gd["call_kinds"], gd["call_values"]
     keep = [int(k) for k in gd["keep"]]
-    (x, F, Gain, Gdiv, Gavg, T), kinds, values, taps = _logged_gain_run(f, h, L, x0, iters, [pos[k] for k in keep])
+    (x, F, Gain, Gdiv, Gavg, T), kinds, values, taps = _logged_gain_run(f, h, L, x0, iters, [pos[k] for k in keep], overlap)
     assert len(F) == iters
     differs = np.flatnonzero(np.abs(Gain - ref_gain) > 1e-12 * np.abs(ref_gain))
     stable = int(differs[0]) if differs.size else iters           # iterations [0, stable) made the same decisions
@@ -633,10 +646,13 @@ def test_large_abpg_gain_300_iterations_2048x32768(large, acc):
     assert np.all(np.diff(F) < 1e-9 * np.abs(F[:-1]))
 
 
-def test_large_abpg_1000_iterations_2048x32768(large, acc):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_large_abpg_1000_iterations_2048x32768(large, acc, overlap):
     """The north-star horizon at the headline size: 1000 iterations of ABPG(gamma=2, theta_eq=True) at
     D_opt_design(2048,32768) against the real reference (oracle/gen_golden.py --only-large-abpg-1000, about three hours
-    of CPU; accbpg/algorithms.py:118-193).  l_inf(x_k) < 1e-9 at k = 250, 500, 750 and 1000, every F[k] to 1e-9."""
+    of CPU; accbpg/algorithms.py:118-193).  l_inf(x_k) < 1e-9 at k = 250, 500, 750 and 1000, every F[k] to 1e-9.  Run on both
+    evaluation paths: F[k] on the solver's stream, and the package default (F[k] on the second handle and stream beside
+    the gradient evaluation, its factorisation in small launches)."""
     import os
     if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "large_abpg_1000.npz")):
         pytest.skip("tests/golden/large_abpg_1000.npz not generated")
@@ -644,30 +660,13 @@ def test_large_abpg_1000_iterations_2048x32768(large, acc):
     gd = golden("large_abpg_1000")
     iters = int(gd["iters"])
     keep = sorted(int(k) for k in gd["keep"])
-    kept, count = {}, [0]
-    value = f.__call__
-
-    class Tap:
-        """Pass-through noting the argument of value call k = the iterate x_k (accbpg/algorithms.py:135)."""
-        m, n, H = f.m, f.n, f.H
-        device = f.device
-        _overlap = False
-        _lin = False
-
-        def __call__(self, x):
-            if count[0] in keep:
-                kept[count[0]] = x.detach().clone()
-            count[0] += 1
-            return f.func_grad(x, 0)
-
-        def func_grad(self, x, flag=2):
-            return f.func_grad(x, flag)
-
-        def gradient(self, x):
-            return f.func_grad(x, 1)
-
+    # the argument of value call k = the iterate x_k (accbpg/algorithms.py:135): one value and one gradient
+    # evaluation per iteration, so it is oracle call 2k
+    tap = _LoggedObjective(f, overlap, [2 * k for k in keep])
     from accbpg_and_fw_amd.algorithms import ABPG
-    x, F, G, T = ABPG(Tap(), h, L, torch.from_numpy(x0).cuda(), gamma=2.0, maxitrs=iters, theta_eq=True, verbose=False)
+    x, F, G, T = ABPG(tap, h, L, torch.from_numpy(x0).cuda(), gamma=2.0, maxitrs=iters, theta_eq=True, verbose=False)
+    assert tap.async_values == (iters if overlap else 0)
+    kept = {k: tap.taps[2 * k] for k in keep}
     x = x.cpu().numpy() if isinstance(x, torch.Tensor) else x
     assert len(F) == iters
     gaps = {k: float(np.max(np.abs(kept[k].cpu().numpy() - gd["x_%d" % k]))) for k in keep}
@@ -1165,6 +1164,98 @@ def test_config5_shard_shape_properties(acc):
     del V, f
 
 
+def test_m8192_matches_reference_golden(acc):
+    """BASELINE config 5's m against the REAL reference: D_opt_design(8192,16400,seed 10) -- 128 block columns in the
+    two-level Cholesky, seven levels of inverse merges, a ragged last column tile in the gradient product -- func_grad at
+    x0 and at a random point, and three ABPG iterations (oracle/gen_golden.py --only-m8192; accbpg/functions.py:43-59,
+    accbpg/algorithms.py:94-180), on the plain objective AND through eight logical shards (unequal slices: 16400 = 8 *
+    2050) with the all-reduce replaced by an in-process sum of the packed triangles."""
+    from accbpg_and_fw_amd.sharded import LogicalShards
+    gd = golden("percall_8192x16400")
+    m, n = int(gd["m"]), int(gd["n"])
+    V = torch.from_numpy(gaussian_design(m, n, int(gd["seed"]))).cuda()
+    x0 = np.ones(n) / n
+    f = acc.DOptimalObj(V)
+    fs = LogicalShards(V, 8)
+    for obj, name in ((f, "plain"), (fs, "8 logical shards")):
+        f0, g0 = obj.func_grad(x0, 2)
+        fx, g = obj.func_grad(gd["x"], 2)
+        print("%s: rel gap f0 %.2e f %.2e, g0 %.2e g %.2e" % (
+            name, abs(f0 - float(gd["f0"])) / abs(float(gd["f0"])), abs(fx - float(gd["f"])) / abs(float(gd["f"])),
+            np.max(np.abs(g0 - gd["g0"]) / np.abs(gd["g0"])), np.max(np.abs(g - gd["g"]) / np.abs(gd["g"]))))
+        assert abs(f0 - float(gd["f0"])) < 1e-11 * abs(float(gd["f0"]))
+        assert abs(fx - float(gd["f"])) < 1e-11 * abs(float(gd["f"]))
+        np.testing.assert_allclose(g0, gd["g0"], rtol=1e-11)
+        np.testing.assert_allclose(g, gd["g"], rtol=1e-11)
+        assert obj(gd["x"]) == pytest.approx(float(gd["f"]), rel=1e-11)
+    h = acc.BurgEntropySimplex()
+    iters = int(gd["iters"])
+    for obj in (f, fs):
+        x, F, G, T = acc.ABPG(obj, h, 1.0, x0, gamma=2, maxitrs=iters, theta_eq=True, verbose=False)
+        assert np.max(np.abs(x - gd["abpg_x"])) < 1e-12
+        _close(F, gd["abpg_F"], 1e-11)
+    del f, fs, V
+
+
+def test_config5_full_size_8192x262144(acc, O):
+    """BASELINE config 5 at ITS size on one GPU: D_opt_design-shaped (8192,262144), V = 16 GiB resident (standard normal,
+    generated on the device).  The sharded evaluation -- eight logical shards, each rank's packed Gram triangle and x >= 0
+    count summed in process where RCCL would all-reduce them, replicated two-level Cholesky, per-shard gradient slices --
+    against the unsharded objective on the same V: f to 1e-11, g to rtol 1e-11; the trace identity sum_i x_i (-g_i) = m and
+    f(c x) = f(x) - m log c; the reference's x >= 0 assertion from one bad entry in one shard; the multi-workgroup Burg prox
+    at n = 262144 against the oracle's scalar loop; three ABPG iterations sharded vs unsharded to l_inf < 1e-12; and
+    accbpg_dopt_shard_* (RCCL inside the library) on a communicator of one rank at this size, bit for bit the staged
+    evaluation."""
+    from accbpg_and_fw_amd.sharded import LogicalShards, NativeShardedDOptimalObj, native_unique_id
+    m, n, parts = 8192, 262144, 8
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    V = torch.randn(m, n, dtype=torch.float64, device="cuda", generator=gen)
+    x = torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) + 0.1
+    x /= x.sum()
+    f = acc.DOptimalObj(V)
+    f1, g1 = f.func_grad(x, 2)
+    assert np.isfinite(f1)
+    assert float(-(x * g1).sum()) == pytest.approx(m, rel=1e-10)
+    assert f(2.5 * x) == pytest.approx(f1 - m * np.log(2.5), rel=1e-12)
+    fs = LogicalShards(V, parts)
+    f2, g2 = fs.func_grad(x, 2)
+    print("sharded vs unsharded at (8192,262144): rel gap f %.2e, g %.2e"
+          % (abs(f1 - f2) / abs(f1), float(((g2 - g1).abs() / g1.abs()).max())))
+    assert abs(f1 - f2) < 1e-11 * abs(f1)
+    assert float(((g2 - g1).abs() / g1.abs()).max()) < 1e-11
+    assert fs(x) == f2
+    assert float(-(x * g2).sum()) == pytest.approx(m, rel=1e-10)
+    for bad_value in (-1e-9, float("nan")):
+        xb = x.clone()
+        xb[n - 2] = bad_value                                    # one entry, in the last shard only
+        with pytest.raises(AssertionError):
+            fs(xb)
+        with pytest.raises(AssertionError):
+            f(xb)
+    # the prox of the solver step at this n (several workgroups; accbpg/functions.py:336-356)
+    h = acc.BurgEntropySimplex()
+    z = h.div_prox_map(x, g1, 1.0)
+    zo = O.BurgSimplexOracle().div_prox_map(x.cpu().numpy(), g1.cpu().numpy(), 1.0)
+    np.testing.assert_allclose(z.cpu().numpy(), zo, rtol=1e-11)
+    assert abs(float(z.sum()) - 1) <= 1.001e-8 and float(z.min()) > 0
+    x0 = torch.full((n,), 1.0 / n, dtype=torch.float64, device="cuda")
+    xa, Fa, Ga, Ta = acc.ABPG(f, h, 1.0, x0, gamma=2, maxitrs=3, verbose=False)
+    xb, Fb, Gb, Tb = acc.ABPG(fs, h, 1.0, x0, gamma=2, maxitrs=3, verbose=False)
+    assert float((xa - xb).abs().max()) < 1e-12
+    np.testing.assert_allclose(Fb, Fa, rtol=1e-12)
+    del fs
+    torch.cuda.empty_cache()
+    fn = NativeShardedDOptimalObj(V, n, 1, 0, native_unique_id())
+    f3, g3 = fn.func_grad(x, 2)
+    f4, g4 = LogicalShards(V, 1).func_grad(x, 2)
+    assert f3 == f4
+    assert torch.equal(g3, g4)
+    assert abs(f3 - f1) < 1e-11 * abs(f1)
+    assert float(((g3 - g1).abs() / g1.abs()).max()) < 1e-11
+    del fn, f, V
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("shape", [(300, 3000), (1024, 4096), (4160, 8320)])
 def test_runs_are_bitwise_reproducible(acc, shape):
     """Fixed reduction trees, a deterministic stream-K fix-up order and no unordered atomics (the
@@ -1179,10 +1270,11 @@ def test_runs_are_bitwise_reproducible(acc, shape):
             np.testing.assert_array_equal(p, q)
 
 
-@pytest.mark.parametrize("shape", [(300, 3000), (512, 8192), (1024, 4096)])
+@pytest.mark.parametrize("shape", [(300, 3000), (512, 8192), (1024, 4096), (1536, 4096), (2048, 8192)])
 def test_overlapped_value_evaluation_is_identical(acc, shape):
     """The default: F[k] = f(x) on a side stream beside func_grad(y).  Same kernels on the same data, so
-    the whole run is bitwise identical to the one with both evaluations on the solver's stream."""
+    the whole run is bitwise identical to the one with both evaluations on the solver's stream.  The last two
+    shapes lie above the size (m > 1408) from which the side handle factors in small launches."""
     f, h, L, x0 = acc.D_opt_design(shape[0], shape[1], randseed=21)
     assert f._overlap                                           # on unless switched off
     f.overlap_values(False)
