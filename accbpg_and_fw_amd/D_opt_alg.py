@@ -136,9 +136,14 @@ def D_opt_FW_steps(V, x0, eps, maxitrs, verbose=True, verbskip=1):
 
 
 # How often D_opt_FW_away refactors the maintained inverse for F[k] = log det(H_k) when the caller does not say
-# (``logdet_refresh=None``).  See D_opt_FW_away.
-LOGDET_REFRESH_DEFAULT = 1
-LOGDET_RING_DEFAULT = 1
+# (``logdet_refresh=None``), and how many factorisations are in flight when it does so every iteration.  Decided with
+# numbers (tools/fw_away_modes.py, profiles/r03_fw_away_modes.json; D_opt_design(2048,32768), one MI355X): anchoring
+# every 16th iteration leaves F[k] within 1.1e-13 (absolute; |F| ~ 50) of the every-iteration factorisation over 1000
+# and over 20000 iterations -- less than that run's own distance from the reference's trace (1e-14 relative) -- with
+# bit-identical iterates and gaps, at 5600-5900 iterations/s against 2800-2900 for the every-iteration form with three
+# factorisations in flight (1520 with one).  The every-iteration form stays one keyword away (logdet_refresh=1).
+LOGDET_REFRESH_DEFAULT = 16
+LOGDET_RING_DEFAULT = 3
 
 
 def D_opt_FW_away(V, x0, eps, maxitrs, verbose=True, verbskip=1, logdet_refresh=None, logdet_ring=None):

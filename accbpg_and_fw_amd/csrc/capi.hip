@@ -390,6 +390,7 @@ extern "C" int accbpg_debug_chol_variant(accbpg_dopt* h, int bits) {
     if (bits & 2048) h->chol_tiles_off = true;   // a forced scheme of the launch-per-column kernels
     h->chol_stall_test = (bits & 128) ? 1 : 0;  // bit 7: make the one-launch kernel time out (exercises the redo); short limit
     h->chol_spin_limit = (bits & 128) ? 200000 : 20000000;
+    h->kern_variant = (bits >> 30) & 3;       // bits 30..31: schedule of the direct-to-LDS Gram / gradient kernels
     if (bits & 256) h->use_glds = false;      // bit 8: register-staged Gram / gradient kernels
     if (bits & 512) h->use_glds = true;
     if (bits & 2048) {                                                    // bit 11: two-level threshold (block columns)

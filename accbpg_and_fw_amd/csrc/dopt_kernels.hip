@@ -241,6 +241,69 @@ __device__ __forceinline__ void gram_streamk_glds_body(
         static_assert(T::MI == 4, "group 0 is dealt out over four fragment rows");
         constexpr int NP = T::G_NA + T::G_NB;
         constexpr int P1 = (NP + 2) / 3, P2 = 2 * P1 < NP ? 2 * P1 : NP;
+        if constexpr (GV & 32) {
+            // Dealt-out schedule: nothing is issued as a block at a group boundary.  A fragment group is sixteen pairs
+            // of MFMAs; behind every pair goes ONE small thing -- a part of the next group's LDS reads, two of the
+            // loads of stage ks+2, the multiply that scales the next fragment row -- so that each of them issues in
+            // the shadow of the 128 cycles the pair keeps the matrix pipe busy, and the pipe never waits behind a
+            // block of reads (seven LDS instructions, four multiplies and their address arithmetic per group before:
+            // about 8 % of the kernel by the read ablations).  The barrier sits in the MIDDLE of the last group, and
+            // the first fragments of the next stage are read behind it under that group's second half.
+#pragma unroll 1
+            for (int64_t ks = kb; ks < ke; ++ks) {
+                int nx2 = cur + 2;
+                if (nx2 >= 3) nx2 -= 3;
+                int nx1 = cur + 1;
+                if (nx1 >= 3) nx1 -= 3;
+                const double* st = lds + cur * T::G_STAGE;
+                const double* st1 = lds + nx1 * T::G_STAGE;
+                double* nst = lds + nx2 * T::G_STAGE;            // last read in step ks-1
+                const int64_t k2 = min(ks + 2, klast) * BK;
+                // group g (fragment set S = g & 1): its MFMAs, and the reads of group g+1 into the other set
+                auto group = [&](auto gtag) {
+                    constexpr int g = decltype(gtag)::value;
+                    constexpr int S = g & 1, NS = S ^ 1;
+                    static_for<0, 16>([&](auto qtag) {
+                        constexpr int q = decltype(qtag)::value;
+                        constexpr int I = q >> 2, P = q & 3;
+                        if constexpr (P == 0) t.template scale_row<S, I>();
+                        __builtin_amdgcn_sched_barrier(0);
+                        // placement B (GV & 64): reads early in the group (behind pairs 1..7), the loads of group 0
+                        // behind pairs 8..14, the barrier behind the first fragment row of the last group
+                        constexpr bool PB = (GV & 64) != 0;
+                        constexpr int QBAR = PB ? 4 : 8;
+                        if constexpr (g == 3 && q == QBAR) {
+                            // stage ks+1 (issued one step ago) has landed: all but the newest NLD loads done;
+                            // lgkmcnt(0): this wave's reads of stage ks are complete before others may overwrite it
+                            asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLD) : "memory");
+                            __builtin_amdgcn_s_barrier();
+                        }
+                        t.template mma_pair<S, I, P>();
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (g < 3) {
+                            constexpr int rp = PB ? q - 1 : (((q & 1) == 1) ? (q >> 1) : -1);   // read part behind this pair
+                            if constexpr (rp >= 0 && rp < 7) t.template read_part_g<NS, true, rp>(st, g + 1);
+                            constexpr int lp = PB ? q - 8 : (((q & 1) == 0) ? (q >> 1) : -1);   // load slot behind this pair
+                            if constexpr (g == 0 && lp >= 0) {
+                                constexpr int p0 = 2 * lp;
+                                if constexpr (p0 < NP) t.glds_issue_range(k2, k2, nst, p0, p0 + 2 < NP ? p0 + 2 : NP);
+                                if constexpr (p0 == NP || (p0 + 1 == NP)) t.glds_x(x, k2, nst);
+                            }
+                        } else {
+                            // (after the last step this reads the redundant, already landed copy of stage klast)
+                            constexpr int rp = q - QBAR - (PB ? 1 : 0);
+                            if constexpr (rp >= 0 && rp < 7) t.template read_part_g<NS, true, rp>(st1, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                };
+                group(std::integral_constant<int, 0>{});
+                group(std::integral_constant<int, 1>{});
+                group(std::integral_constant<int, 2>{});
+                group(std::integral_constant<int, 3>{});
+                cur = nx1;
+            }
+        } else {
 #pragma unroll 1
         for (int64_t ks = kb; ks < ke; ++ks) {
             int nx2 = cur + 2;
@@ -289,6 +352,7 @@ __device__ __forceinline__ void gram_streamk_glds_body(
             __builtin_amdgcn_sched_barrier(0);
             t.template mma_frag<1>();
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // tail loads / reads retire before LDS is reused
         if (sg.whole) {
@@ -501,7 +565,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void colnorm_kernel(
 }
 
 // Direct-to-LDS version of the gradient kernel for interior sizes.
-template <class T>
+template <class T, int CV = 0>
 __device__ __forceinline__ void colnorm_glds_body(
     const double* __restrict__ W, int64_t ldw, const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n,
     double* __restrict__ out, double sign) {
@@ -534,6 +598,62 @@ __device__ __forceinline__ void colnorm_glds_body(
         __builtin_amdgcn_s_barrier();
         int cur = 0;
         t.template read_frag_g<0, false>(lds, 0);
+        if constexpr (CV & 32) {
+            // dealt-out schedule, as in the Gram kernel (gram_streamk_glds_body, GV & 32)
+            constexpr int NP = T::G_NA + T::G_NB;
+#pragma unroll 1
+            for (int64_t ks = 0; ks < ksteps; ++ks) {
+                int nx2 = cur + 2;
+                if (nx2 >= 3) nx2 -= 3;
+                int nx1 = cur + 1;
+                if (nx1 >= 3) nx1 -= 3;
+                const double* st = lds + cur * T::G_STAGE;
+                const double* st1 = lds + nx1 * T::G_STAGE;
+                double* nst = lds + nx2 * T::G_STAGE;
+                const int64_t kd = ks * BK - row0;
+                int mi_lo = 0;
+                if (kd > 0) {
+                    const int64_t num = kd - 15 - 16 * wm;
+                    mi_lo = num > 0 ? (int)((num + 16 * T::WAVES_M - 1) / (16 * T::WAVES_M)) : 0;
+                }
+                const int64_t k2 = min(ks + 2, klast) * BK;
+                auto group = [&](auto gtag) {
+                    constexpr int g = decltype(gtag)::value;
+                    constexpr int S = g & 1, NS = S ^ 1;
+                    static_for<0, 16>([&](auto qtag) {
+                        constexpr int q = decltype(qtag)::value;
+                        constexpr int I = q >> 2, P = q & 3;
+                        constexpr bool PB = (CV & 64) != 0;
+                        constexpr int QBAR = PB ? 4 : 8;
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (g == 3 && q == QBAR) {
+                            asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLD) : "memory");
+                            __builtin_amdgcn_s_barrier();
+                        }
+                        t.template mma_pair<S, I, P>(mi_lo);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (g < 3) {
+                            constexpr int rp = PB ? q - 1 : (((q & 1) == 1) ? (q >> 1) : -1);
+                            if constexpr (rp >= 1 && rp < 7) t.template read_part_g<NS, false, rp>(st, g + 1);
+                            constexpr int lp = PB ? q - 8 : (((q & 1) == 0) ? (q >> 1) : -1);
+                            if constexpr (g == 0 && lp >= 0) {
+                                constexpr int p0 = 2 * lp;
+                                if constexpr (p0 < NP) t.glds_issue_range(k2, k2 * ldv, nst, p0, p0 + 2 < NP ? p0 + 2 : NP);
+                            }
+                        } else {
+                            constexpr int rp = q - QBAR - (PB ? 1 : 0);
+                            if constexpr (rp >= 1 && rp < 7) t.template read_part_g<NS, false, rp>(st1, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                };
+                group(std::integral_constant<int, 0>{});
+                group(std::integral_constant<int, 1>{});
+                group(std::integral_constant<int, 2>{});
+                group(std::integral_constant<int, 3>{});
+                cur = nx1;
+            }
+        } else {
 #pragma unroll 1
         for (int64_t ks = 0; ks < ksteps; ++ks) {
             int nx2 = cur + 2;
@@ -579,6 +699,7 @@ __device__ __forceinline__ void colnorm_glds_body(
             t.template mma_frag<1>(mi_lo);
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int j = 0; j < T::NI; ++j) {
@@ -611,11 +732,11 @@ __device__ __forceinline__ void colnorm_glds_body(
     }
 }
 
-template <class T>
+template <class T, int CV = 0>
 __global__ __launch_bounds__(NTHREADS, 1) void colnorm_glds_kernel(
     const double* __restrict__ W, int64_t ldw, const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n,
     double* __restrict__ out, double sign) {
-    colnorm_glds_body<T>(W, ldw, V, ldv, m, n, out, sign);
+    colnorm_glds_body<T, CV>(W, ldw, V, ldv, m, n, out, sign);
 }
 template <class T>
 __global__ __launch_bounds__(NTHREADS, 1) void colnorm_glds_batch_kernel(
@@ -2305,6 +2426,10 @@ int build_plans(accbpg_dopt* h) {
     ACC_TRY(set_lds(chol_syrk_kernel, SYRK_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>>, TileBig<false, false>::G_LDS_BYTES));
     ACC_TRY(set_lds(colnorm_glds_kernel<TileBig<true, false>>, TileBig<true, false>::G_LDS_BYTES + 4 * 128 * 8));
+    ACC_TRY(set_lds(colnorm_glds_kernel<TileBig<true, false>, 32>, TileBig<true, false>::G_LDS_BYTES + 4 * 128 * 8));
+    ACC_TRY(set_lds(colnorm_glds_kernel<TileBig<true, false>, 96>, TileBig<true, false>::G_LDS_BYTES + 4 * 128 * 8));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>, 32>, TileBig<false, false>::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>, 96>, TileBig<false, false>::G_LDS_BYTES));
     ACC_TRY(set_lds(gemm_big_kernel<TileBig<true>>, TileBig<true>::LDS_BYTES));
     ACC_TRY(set_lds(gemm_big_kernel<TileBig<false>>, TileBig<false>::LDS_BYTES));
     return ACCBPG_OK;
@@ -2314,7 +2439,13 @@ template <class T>
 static void gram_launch_t(accbpg_dopt* h, const double* x, double* gram) {
     prof_begin(h, PROF_GRAM);
     if constexpr (!T::EDGE && T::BM == 256) {
-        if (h->use_glds || h->has_duals)
+        if ((h->use_glds || h->has_duals) && h->kern_variant == 1)
+            gram_streamk_glds_kernel<T, 32><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
+                h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m);
+        else if ((h->use_glds || h->has_duals) && h->kern_variant == 2)
+            gram_streamk_glds_kernel<T, 96><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
+                h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m);
+        else if (h->use_glds || h->has_duals)
             gram_streamk_glds_kernel<T><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
                 h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m);
         else
@@ -2357,6 +2488,8 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
             case 15: ACC_LAUNCH_G(8); break;
             case 16: ACC_LAUNCH_G(7); break;
             case 17: ACC_LAUNCH_G(16); break;
+            case 18: ACC_LAUNCH_G(32); break;
+            case 19: ACC_LAUNCH_G(96); break;
             case 0: ACC_LAUNCH_VAR(0); break;
             case 1: ACC_LAUNCH_VAR(1); break;
             case 2: ACC_LAUNCH_VAR(2); break;
@@ -2372,6 +2505,8 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
     ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 8>, T::G_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 7>, T::G_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 16>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 32>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 96>, T::G_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 1>, T::LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 2>, T::LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 3>, T::LDS_BYTES));
@@ -2569,8 +2704,15 @@ int launch_colnorm(accbpg_dopt* h, const double* W, double* out, double sign) {
         const bool interior = vw && h->vec_ok && (h->m % 256 == 0) && (h->n % 128 == 0);
         if (interior && h->use_glds) {
             using T = TileBig<true, false>;
-            colnorm_glds_kernel<T><<<(int)(h->n / T::BN), NTHREADS, T::G_LDS_BYTES + 4 * T::BN * 8, h->stream>>>(
-                W, h->m, h->V, h->ldv, h->m, h->n, out, sign);
+            if (h->kern_variant == 1)
+                colnorm_glds_kernel<T, 32><<<(int)(h->n / T::BN), NTHREADS, T::G_LDS_BYTES + 4 * T::BN * 8, h->stream>>>(
+                    W, h->m, h->V, h->ldv, h->m, h->n, out, sign);
+            else if (h->kern_variant == 2)
+                colnorm_glds_kernel<T, 96><<<(int)(h->n / T::BN), NTHREADS, T::G_LDS_BYTES + 4 * T::BN * 8, h->stream>>>(
+                    W, h->m, h->V, h->ldv, h->m, h->n, out, sign);
+            else
+                colnorm_glds_kernel<T><<<(int)(h->n / T::BN), NTHREADS, T::G_LDS_BYTES + 4 * T::BN * 8, h->stream>>>(
+                    W, h->m, h->V, h->ldv, h->m, h->n, out, sign);
         } else if (interior) colnorm_launch_t<TileBig<true, false>>(h, W, out, sign, vw);
         else colnorm_launch_t<TileBig<true, true>>(h, W, out, sign, vw);
     } else {

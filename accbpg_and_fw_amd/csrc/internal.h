@@ -168,6 +168,7 @@ struct accbpg_dopt {
     bool fw_part_away = false;  // support threshold they were computed for
 
     bool use_glds = true;       // direct-to-LDS staging for interior big tiles (debug switch)
+    int kern_variant = 0;       // schedule of the direct-to-LDS Gram / gradient kernels (development switch)
     bool diag_inv_ready = false;  // the last factorisation wrote the inverses of the diagonal blocks into Wbuf
     bool has_duals = false;     // the Gram tile list holds dual diagonal tiles (direct-to-LDS kernel only)
     int chol_nk = 8;            // block columns per outer panel of the two-level scheme

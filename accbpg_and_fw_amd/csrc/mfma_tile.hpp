@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace accbpg {
 
@@ -41,6 +42,15 @@ __device__ __forceinline__ d2 load2_guard(const double* __restrict__ p, bool row
         v.y = (row_ok && k + 1 < K) ? p[1] : 0.0;
     }
     return v;
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
 }
 
 // BM x BN workgroup tile, WM x WN wave tile, B either k-major (B[k][col], "NN") or
@@ -361,6 +371,49 @@ struct Tile {
             for (int j = 0; j < NI; ++j) fb[SET][j] = bs[j * 16 * BK];
         }
         if constexpr (SCALE) fx[SET] = stage[G_A + G_B + 4 * kk + lq];   // applied by scale_frag<SET>()
+    }
+
+    // The same fragment group in seven parts, so that the caller can deal the LDS reads out between MFMAs instead of
+    // issuing them as one block at a group boundary (where the matrix pipe would sit idle behind its last MFMA while
+    // the block issues).  Parts in the order the next group needs them: 0 = x (SCALE), 1 = A rows 0,1, 2..5 = B
+    // column fragments 0,1 / 2,3 / 4,5 / 6,7, 6 = A rows 2,3.
+    template <int SET, bool SCALE, int PART>
+    __device__ __forceinline__ void read_part_g(const double* __restrict__ stage, int kk) {
+        static_assert(MI == 4 && NI == 8, "parts are laid out for the 64 x 128 wave tile");
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+        const int lr = lane & 15, lq = lane >> 4;
+        const int sw = (lr >> 1) & 7;
+        const int koff = 2 * ((2 * kk + (lq >> 1)) ^ sw) + (lq & 1);
+        if constexpr (PART == 0) {
+            if constexpr (SCALE) fx[SET] = stage[G_A + G_B + 4 * kk + lq];
+        } else if constexpr (PART == 1 || PART == 6) {
+            const double* as = stage + (16 * wm + lr) * BK + koff;
+            constexpr int i0 = (PART == 1) ? 0 : 2;
+            fa[SET][i0] = as[i0 * 16 * WAVES_M * BK];
+            fa[SET][i0 + 1] = as[(i0 + 1) * 16 * WAVES_M * BK];
+        } else {
+            constexpr int j0 = 2 * (PART - 2);
+            if constexpr (BKM) {
+                const double* bs = stage + G_A + (4 * kk + lq) * BN + wn * WN + lr;
+                fb[SET][j0] = bs[16 * (j0 ^ (lq & 1))];
+                fb[SET][j0 + 1] = bs[16 * ((j0 + 1) ^ (lq & 1))];
+            } else {
+                const double* bs = stage + G_A + (wn * WN + lr) * BK + koff;
+                fb[SET][j0] = bs[j0 * 16 * BK];
+                fb[SET][j0 + 1] = bs[(j0 + 1) * 16 * BK];
+            }
+        }
+    }
+    template <int SET, int I>
+    __device__ __forceinline__ void scale_row() { fa[SET][I] *= fx[SET]; }
+    // MFMAs (I, 2P) and (I, 2P+1) of a fragment group
+    template <int SET, int I, int P>
+    __device__ __forceinline__ void mma_pair(int mi_lo = 0) {
+        if (I >= mi_lo) {
+            acc[I][2 * P] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET][I], fb[SET][2 * P], acc[I][2 * P], 0, 0, 0);
+            acc[I][2 * P + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET][I], fb[SET][2 * P + 1], acc[I][2 * P + 1], 0, 0, 0);
+        }
     }
 
     // ---- "dual" diagonal tile (Gram matrix only) ---------------------------------------------

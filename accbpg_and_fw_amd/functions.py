@@ -540,7 +540,7 @@ class BurgEntropy(LegendreFunction):
             ws = _Workspace.get(n, xd.device)
             rc = _lib.load().accbpg_burg_divergence(_ptr(xd), _ptr(yd), n, C.byref(out), _ptr(ws), _stream())
         _lib.check(rc, "accbpg_burg_divergence", "Entries of x or y not positive.")
-        return out.value
+        return np.float64(out.value)                            # a NumPy scalar, as the reference's sum is (:253)
 
     _kind = 0       # closed-form variant of accbpg_burg_reg_div_prox
     lamda = 0
@@ -678,7 +678,10 @@ def ls_terms(g, x, y, z=None, z1=None):
         rc = _lib.load().accbpg_ls_terms(_ptr(g), _ptr(x), _ptr(y), _ptr(z), _ptr(z1), x.numel(), out, _ptr(ws),
                                          _stream())
     _lib.check(rc, "accbpg_ls_terms", "Entries of x or y not positive.")
-    return out[0], out[1], out[2]
+    # NumPy scalars, as the reference's sums are (accbpg/functions.py:253): D(x+,y) / D(z+,z) with D(z+,z) == 0 --
+    # an iterate that has stopped moving -- is then inf or nan with a warning, as in the reference, not an exception
+    # (the stopping rule dzz < epsilon right behind it ends the run, accbpg/algorithms.py:155,174)
+    return np.float64(out[0]), np.float64(out[1]), np.float64(out[2])
 
 
 def vec_min_sum(x):

@@ -394,6 +394,53 @@ def test_fw_trajectories(acc, tag):
     _close(F2[:k], F[:k], 1e-9)
 
 
+@pytest.mark.parametrize("shape", [(64, 512), (256, 4096), (1536, 4096)])
+def test_fw_away_logdet_forms_agree(acc, O, shape):
+    """F[k] = log det(H_k) of D_opt_FW_away (accbpg/D_opt_alg.py:136) is a logged value; the forms it can be produced in
+    -- a fresh factorisation every iteration with 1 or 3 of them in flight beside the steps, anchored every R-th
+    iteration with log-space steps in between (the default, R = 16), never refactored -- leave iterates, gaps and step
+    choices BIT-identical, give the identical F where every iteration is factored, and F within 1e-12 (1 + |F|) of that
+    otherwise; and all of them follow the oracle's trace."""
+    m, n = shape
+    V = gaussian_design(m, n, 19)
+    x0 = np.ones(n) / n
+    iters = 300
+    f = acc.DOptimalObj(V)
+    ref = acc.D_opt_FW_away(f, x0, -1.0, iters, verbose=False, logdet_refresh=1, logdet_ring=1)
+    xo, Fo, SPo, SNo, To = O.D_opt_FW_away(V, x0, -1.0, iters)
+    _close(ref[1], Fo, 1e-9); _close(ref[2], SPo, 1e-7)
+    assert np.max(np.abs(ref[0] - xo)) < 1e-10
+    for kw in (dict(logdet_refresh=1, logdet_ring=3), dict(logdet_refresh=1, logdet_ring=2), dict(), dict(logdet_refresh=16),
+               dict(logdet_refresh=7), dict(logdet_refresh=64), dict(logdet_refresh=1000), dict(logdet_refresh=0)):
+        x, F, SP, SN, T = acc.D_opt_FW_away(f, x0, -1.0, iters, verbose=False, **kw)
+        np.testing.assert_array_equal(x, ref[0])
+        np.testing.assert_array_equal(SP, ref[2])
+        np.testing.assert_array_equal(SN, ref[3])
+        assert len(F) == iters
+        if kw.get("logdet_refresh") == 1:
+            np.testing.assert_array_equal(F, ref[1])
+        else:
+            assert np.max(np.abs(F - ref[1]) / (1 + np.abs(ref[1]))) < 1e-12, kw
+    # an evaluation on the same handle while factorisations are in flight, and a run that ends early
+    from accbpg_and_fw_amd.D_opt_alg import D_opt_FW_away_steps
+    gen = D_opt_FW_away_steps(f, x0, -1.0, 50, verbose=False, logdet_refresh=1, logdet_ring=3)
+    for _ in range(10):
+        next(gen)
+    fv, g = f.func_grad(x0, 2)                                   # while three factorisations are in flight
+    fo, go = O.DOptOracle(V).func_grad(x0, 2)
+    assert abs(fv - fo) < 1e-11 * max(1.0, abs(fo))
+    np.testing.assert_allclose(g, go, rtol=1e-10)
+    gen.close()                                                  # abandoned with factorisations in flight
+    again = acc.D_opt_FW_away(f, x0, -1.0, iters, verbose=False, logdet_refresh=1, logdet_ring=1)
+    np.testing.assert_array_equal(again[1], ref[1])
+    # the stopping rule ends a run where the reference's does (eps large enough to be met)
+    if m <= 64:
+        xs, Fs, SPs, SNs, Ts = acc.D_opt_FW_away(f, x0, 0.3, 3000, verbose=False)
+        xr, Fr, SPr, SNr, Tr = O.D_opt_FW_away(V, x0, 0.3, 3000)
+        assert len(Fs) == len(Fr) and 1 < len(Fs) < 3000
+        _close(Fs, Fr, 1e-9)
+
+
 def test_fw_housing_and_state(acc):
     gd = golden("housing")
     V = gd["V"]
