@@ -99,6 +99,7 @@ _SIGS = {
     "accbpg_mfma_f64_peak": (C.c_int, [C.c_int, C.POINTER(C.c_double), _P]),
     "accbpg_dopt_factor_in_small_launches": (C.c_int, [_P, C.c_int]),
     "accbpg_debug_chol_variant": (C.c_int, [_P, C.c_int]),
+    "accbpg_debug_plan_flags": (C.c_int, [C.c_int]),
     "accbpg_debug_chol_trace": (C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int64)]),
     "accbpg_debug_gram_variant": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "accbpg_test_gemm": (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int64,

@@ -67,6 +67,33 @@ class DOptimalBatch:
             self._views[i] = view
         return self._views[i]
 
+    # ---- kernel-time accounting used by bench.py (rides on instance 0's slots of this batch and of its twin) ----
+    def _handles0(self):
+        hs = [C.c_void_p(self._lib.accbpg_dopt_batch_instance(self._h, 0))]
+        twin = getattr(self, "_twin", None)
+        if twin is not None:
+            hs.append(C.c_void_p(self._lib.accbpg_dopt_batch_instance(twin._h, 0)))
+        return hs
+
+    def profile(self, enable=True):
+        """HIP-event timing of every batched launch on the stream it is launched on (one event pair per kernel family
+        and launch)."""
+        self._prof = bool(enable)
+        for h in self._handles0():
+            self._lib.accbpg_dopt_profile_enable(h, 1 if enable else 0)
+            self._lib.accbpg_dopt_profile_reset(h)
+
+    def profile_read(self):
+        out = {}
+        for idx, name in enumerate(["gram", "cholesky", "trtri", "grad", "gram_fixup", "fw_vpass"]):
+            tot, num = 0.0, 0
+            for h in self._handles0():
+                ms, cnt = C.c_double(0.0), C.c_int64(0)
+                self._lib.accbpg_dopt_profile_read(h, idx, C.byref(ms), C.byref(cnt))
+                tot, num = tot + ms.value, num + cnt.value
+            out[name] = (tot, num)
+        return out
+
     def _mask(self, active):
         if active is None:
             return None, list(range(self.K))
@@ -198,8 +225,9 @@ def ABPG_batch_steps(batch, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=Fa
     for k in range(maxitrs):
         if not any(active):
             break
-        ticket = batch.value_async(X, active) if overlap else None          # :135 (beside the gradients below)
-        fx = None if overlap else batch.func_grad(X, 0, active)
+        side = overlap and not getattr(batch, "_prof", False)                # (kernel timing keeps everything on one stream)
+        ticket = batch.value_async(X, active) if side else None             # :135 (beside the gradients below)
+        fx = None if side else batch.func_grad(X, 0, active)
         now = time.time() - t_start
         for i in range(K):
             if active[i]:
@@ -210,7 +238,7 @@ def ABPG_batch_steps(batch, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=Fa
         one_m = [1 - t for t in theta]
         Y = batch.axpby(one_m, X, theta, Z, active)                         # :147
         Gr = batch.func_grad(Y, 1, active)                                  # :148
-        if overlap:
+        if side:
             fx = batch.value_wait(ticket)
             now = time.time() - t_start
         for i in range(K):
@@ -382,8 +410,9 @@ def ABPG_gain_batch_steps(batch, h, L, x0, gamma, maxitrs, epsilon=1e-14, G0=1, 
     for k in range(maxitrs):
         if not any(active):
             break
-        ticket = batch.value_async(X, active) if overlap else None          # :347 (beside the first gradients below)
-        fx = None if overlap else batch.func_grad(X, 0, active)
+        side = overlap and not getattr(batch, "_prof", False)                # (kernel timing keeps everything on one stream)
+        ticket = batch.value_async(X, active) if side else None             # :347 (beside the first gradients below)
+        fx = None if side else batch.func_grad(X, 0, active)
         now = time.time() - t_start
         G_prev, theta_prev = list(Gs), list(theta)
         for i in range(K):
@@ -405,7 +434,7 @@ def ABPG_gain_batch_steps(batch, h, L, x0, gamma, maxitrs, epsilon=1e-14, G0=1, 
             batch.axpby(one_m, X, theta, Z, search, out=Y)                  # :369
             fy, _ = batch.func_grad(Y, 2, search, out=Gr)                   # :371
             if first_pass:
-                if overlap:
+                if side:
                     fx = batch.value_wait(ticket)
                     now = time.time() - t_start
                 for i in range(K):

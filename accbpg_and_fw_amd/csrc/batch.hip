@@ -93,6 +93,13 @@ extern "C" int accbpg_dopt_batch_create(const double* const* V_dev_host, int K, 
                        (long long)n, (long long)ldv);
         return ACCBPG_ERR_ARG;
     }
+    if (K > BATCH_MAX) {
+        // the active set travels as a fixed-size kernel argument (BatchAct) and the length-n batch kernels refuse
+        // more: one limit for the whole family, stated here instead of an index past the table later
+        set_last_error("accbpg_dopt_batch_create: K=%d instances, at most ACCBPG_BATCH_MAX=%d per batch (use several batches)",
+                       K, BATCH_MAX);
+        return ACCBPG_ERR_ARG;
+    }
     if (!(m < n)) {                                             // DOptimalObj: need m < n   (functions.py:35)
         set_last_error("DOptimalObj: need m < n");
         return ACCBPG_ERR_ASSERT;

@@ -383,6 +383,13 @@ extern "C" int accbpg_dopt_factor_in_small_launches(accbpg_dopt* h, int on) {
     return ACCBPG_OK;
 }
 
+/* Development switch for handles created AFTER the call: bit 0 = plain stream-K ranges of the Gram kernel also where
+ * there are more tiles than workgroups (m >= 4096), instead of whole tiles per workgroup (A/B measurements). */
+extern "C" int accbpg_debug_plan_flags(int flags) {
+    set_plan_flags(flags);
+    return ACCBPG_OK;
+}
+
 extern "C" int accbpg_debug_chol_variant(accbpg_dopt* h, int bits) {
     if (!h) return ACCBPG_ERR_ARG;
     h->chol_dbg = bits & 63;

@@ -272,19 +272,20 @@ __device__ __forceinline__ void gram_streamk_glds_body(
                         // behind pairs 8..14, the barrier behind the first fragment row of the last group
                         constexpr bool PB = (GV & 64) != 0;
                         constexpr int QBAR = PB ? 4 : 8;
-                        if constexpr (g == 3 && q == QBAR) {
+                        if constexpr (g == 3 && q == QBAR && !(GV & 2)) {
                             // stage ks+1 (issued one step ago) has landed: all but the newest NLD loads done;
                             // lgkmcnt(0): this wave's reads of stage ks are complete before others may overwrite it
-                            asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLD) : "memory");
+                            if constexpr (GV & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(NLD) : "memory");
                             __builtin_amdgcn_s_barrier();
                         }
                         t.template mma_pair<S, I, P>();
                         __builtin_amdgcn_sched_barrier(0);
                         if constexpr (g < 3) {
                             constexpr int rp = PB ? q - 1 : (((q & 1) == 1) ? (q >> 1) : -1);   // read part behind this pair
-                            if constexpr (rp >= 0 && rp < 7) t.template read_part_g<NS, true, rp>(st, g + 1);
+                            if constexpr (rp >= 0 && rp < 7 && !(GV & 4)) t.template read_part_g<NS, true, rp>(st, g + 1);
                             constexpr int lp = PB ? q - 8 : (((q & 1) == 0) ? (q >> 1) : -1);   // load slot behind this pair
-                            if constexpr (g == 0 && lp >= 0) {
+                            if constexpr (g == 0 && lp >= 0 && !(GV & 1)) {
                                 constexpr int p0 = 2 * lp;
                                 if constexpr (p0 < NP) t.glds_issue_range(k2, k2, nst, p0, p0 + 2 < NP ? p0 + 2 : NP);
                                 if constexpr (p0 == NP || (p0 + 1 == NP)) t.glds_x(x, k2, nst);
@@ -292,7 +293,7 @@ __device__ __forceinline__ void gram_streamk_glds_body(
                         } else {
                             // (after the last step this reads the redundant, already landed copy of stage klast)
                             constexpr int rp = q - QBAR - (PB ? 1 : 0);
-                            if constexpr (rp >= 0 && rp < 7) t.template read_part_g<NS, true, rp>(st1, 0);
+                            if constexpr (rp >= 0 && rp < 7 && !(GV & 4)) t.template read_part_g<NS, true, rp>(st1, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     });
@@ -2134,6 +2135,11 @@ void prof_end(accbpg_dopt* h, ProfKind k) {
     p.launches += 1;
 }
 
+// development switch read when a handle is created: bit 0 = plain stream-K ranges also where there are more tiles than
+// workgroups (A/B of the whole-tile partition below)
+static int g_plan_flags = 0;
+void set_plan_flags(int flags) { g_plan_flags = flags; }
+
 int build_plans(accbpg_dopt* h) {
     const int64_t m = h->m;
     // ---- Gram tile list (lower tiles) and stream-K partition
@@ -2219,7 +2225,44 @@ int build_plans(accbpg_dopt* h) {
             }
         }
     }
-    if (!aligned) {
+    // More tiles than workgroups (m >= 4096 on 256 CUs; BASELINE config 5: 1056 entries): plain stream-K would hand
+    // every workgroup a contiguous range of 4.1 tiles that starts somewhere inside a tile, so no two workgroups ever
+    // stream the same columns of V at the same time and every k-step of every workgroup comes from HBM (measured at
+    // (8192,262144): 0.67 of the MFMA peak, against 0.84 at (8192,32768) where the Infinity Cache still covers the
+    // offsets).  Instead every workgroup gets `wt` WHOLE tiles, which it walks from k = 0 in step with all the others,
+    // and the workgroups of one XCD (id mod 8 under round-robin placement -- speed only, never correctness) hold, at
+    // every one of the wt phases, a compact 4 x 8 block of tiles: 4 row panels + 8 column panels feed 32 tiles through
+    // that XCD's L2.  The ntiles - wt*grid entries left over are cut into equal pieces, one per workgroup (the
+    // stream-K tail: a few percent of the work).
+    const bool whole_tiles = !(g_plan_flags & 1) && !aligned && h->big && per >= kit && h->ntiles >= grid && grid % 8 == 0 && grid >= 8;
+    if (whole_tiles) {
+        std::stable_sort(tl.begin(), tl.end(), [](const TileRC& a, const TileRC& b) {
+            const int ka[4] = {a.rb / 4, a.cb / 8, a.rb, a.cb}, kb[4] = {b.rb / 4, b.cb / 8, b.rb, b.cb};
+            for (int i = 0; i < 4; ++i)
+                if (ka[i] != kb[i]) return ka[i] < kb[i];
+            return false;
+        });
+        const int wt = h->ntiles / grid, B = grid / 8;
+        const int nbody = wt * grid;
+        std::vector<TileRC> perm(tl);
+        for (int pph = 0; pph < wt; ++pph)
+            for (int xcd = 0; xcd < 8; ++xcd)
+                for (int sl = 0; sl < B; ++sl) {
+                    const int w = 8 * sl + xcd;
+                    perm[(size_t)wt * w + pph] = tl[((size_t)pph * 8 + xcd) * B + sl];
+                }
+        tl.swap(perm);
+        const int64_t tail_total = (int64_t)(h->ntiles - nbody) * kit;
+        const int64_t tail_per = (tail_total + grid - 1) / grid;
+        for (int w = 0; w < grid; ++w) {
+            ranges[((size_t)w * GRAM_RMAX) * 2] = (int64_t)wt * w * kit;
+            ranges[((size_t)w * GRAM_RMAX) * 2 + 1] = (int64_t)wt * (w + 1) * kit;
+            const int64_t t0 = std::min((int64_t)w * tail_per, tail_total), t1 = std::min((int64_t)(w + 1) * tail_per, tail_total);
+            ranges[((size_t)w * GRAM_RMAX + 1) * 2] = (int64_t)nbody * kit + t0;
+            ranges[((size_t)w * GRAM_RMAX + 1) * 2 + 1] = (int64_t)nbody * kit + t1;
+        }
+    }
+    if (!aligned && !whole_tiles) {
         for (int w = 0; w < grid; ++w) {
             ranges[((size_t)w * GRAM_RMAX) * 2] = std::min((int64_t)w * per, total);
             ranges[((size_t)w * GRAM_RMAX) * 2 + 1] = std::min((int64_t)(w + 1) * per, total);
@@ -2236,7 +2279,7 @@ int build_plans(accbpg_dopt* h) {
         const int64_t g = gcd64(per, h->kiters);
         const int64_t D = per / g, dw = h->kiters / g;
         const int nt = (int)tl.size();
-        if (!aligned && h->big && D > 1 && D < nt && nt % D == 0 && dw % 8 == 0) {
+        if (!aligned && !whole_tiles && h->big && D > 1 && D < nt && nt % D == 0 && dw % 8 == 0) {
             const int gs = (int)(nt / D);
             // sequence in which consecutive runs are compact: row-block pairs, then 4 column blocks at a time
             std::vector<TileRC> seq;
@@ -2490,6 +2533,14 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
             case 17: ACC_LAUNCH_G(16); break;
             case 18: ACC_LAUNCH_G(32); break;
             case 19: ACC_LAUNCH_G(96); break;
+            case 20: ACC_LAUNCH_G(97); break;     /* dealt-out, no loads in the loop */
+            case 21: ACC_LAUNCH_G(98); break;     /* dealt-out, no wait + barrier */
+            case 22: ACC_LAUNCH_G(100); break;    /* dealt-out, no fragment reads */
+            case 23: ACC_LAUNCH_G(104); break;    /* dealt-out, barrier without the vmcnt wait */
+            case 24: ACC_LAUNCH_G(103); break;    /* dealt-out, MFMA only */
+            case 25: ACC_LAUNCH_G(102); break;    /* dealt-out, loads only (no barrier, no reads) */
+            case 26: ACC_LAUNCH_G(101); break;    /* dealt-out, barrier only (no loads, no reads) */
+            case 27: ACC_LAUNCH_G(99); break;     /* dealt-out, reads only (no loads, no barrier) */
             case 0: ACC_LAUNCH_VAR(0); break;
             case 1: ACC_LAUNCH_VAR(1); break;
             case 2: ACC_LAUNCH_VAR(2); break;
@@ -2507,6 +2558,14 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
     ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 16>, T::G_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 32>, T::G_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 96>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 97>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 98>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 99>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 100>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 101>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 102>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 103>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 104>, T::G_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 1>, T::LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 2>, T::LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 3>, T::LDS_BYTES));
@@ -2738,10 +2797,15 @@ int launch_gram_batch(accbpg_dopt_batch* b, const BatchAct& act, const double* x
         ACC_TRY(set_lds(gram_streamk_glds_batch_kernel<T>, T::G_LDS_BYTES));
         lds_set = true;
     }
+    // (kernel-time accounting of a batch rides on instance 0's slots: accbpg_dopt_profile_* on accbpg_dopt_batch_instance(b, 0))
+    prof_begin(h0, PROF_GRAM);
     gram_streamk_glds_batch_kernel<T><<<dim3(h0->gram_grid, act.n), NTHREADS, T::G_LDS_BYTES, b->stream>>>(
         b->table, act, h0->ldv, h0->m, h0->n, xbase, ldx, h0->tiles, h0->wg_ranges, h0->kiters, h0->gram_nslot, h0->m);
+    prof_end(h0, PROF_GRAM);
+    prof_begin(h0, PROF_GRAMFIX);
     gram_fixup_batch_kernel<T><<<dim3(h0->ntiles * 2 * T::MI * FIX_PJ, act.n), NTHREADS, 0, b->stream>>>(
         b->table, act, h0->tiles, h0->gram_cstart, h0->gram_contrib, h0->gram_nslot, h0->m, h0->m);
+    prof_end(h0, PROF_GRAMFIX);
     ACC_HIP(hipGetLastError());
     return ACCBPG_OK;
 }
@@ -2750,6 +2814,7 @@ int launch_cholesky_batch(accbpg_dopt_batch* b, const BatchAct& act, bool with_i
     accbpg_dopt* h0 = b->inst[0];
     const int64_t m = h0->m;
     const int T = (int)((m + NB - 1) / NB);
+    prof_begin(h0, PROF_CHOL);
     zero_scalars_batch_kernel<<<act.n, 1024, 0, b->stream>>>(b->table, act, xbase, ldx, h0->n, T * T + 5 * T);
     const int dev = (b->device >= 0 && b->device < 64) ? b->device : 0;
     const int grid_all = h0->chol_tiles_grid * act.n;
@@ -2769,6 +2834,7 @@ int launch_cholesky_batch(accbpg_dopt_batch* b, const BatchAct& act, bool with_i
     chol_tiles_kernel<<<dim3(h0->chol_tiles_grid, act.n), NTHREADS, CT_LDS_BYTES, b->stream>>>(
         CholInst{}, b->chol_table[with_inverse ? 1 : 0], reinterpret_cast<const CholJob*>(h0->chol_jobs), m, m, T,
         h0->chol_spin_limit, 0, act);
+    prof_end(h0, PROF_CHOL);
     ACC_HIP(hipGetLastError());
     {
         const int slot = (int)(ring.issued % TILES_RING);
@@ -2783,6 +2849,7 @@ int launch_cholesky_batch(accbpg_dopt_batch* b, const BatchAct& act, bool with_i
 
 int launch_trtri_batch(accbpg_dopt_batch* b, const BatchAct& act) {
     accbpg_dopt* h0 = b->inst[0];
+    prof_begin(h0, PROF_TRTRI);
     for (const accbpg_dopt::MergeStage& st : h0->merge_stages) {
         const int count = st.end - st.begin;
         if (count <= 0) continue;
@@ -2795,6 +2862,7 @@ int launch_trtri_batch(accbpg_dopt_batch* b, const BatchAct& act) {
             gemm_reduce_batch_kernel<<<dim3(gx, count * act.n), 256, 0, b->stream>>>(b->red_all, b->red_per_inst, st.begin, count, act);
         }
     }
+    prof_end(h0, PROF_TRTRI);
     ACC_HIP(hipGetLastError());
     return ACCBPG_OK;
 }
@@ -2807,8 +2875,10 @@ int launch_colnorm_batch(accbpg_dopt_batch* b, const BatchAct& act, double* gbas
         ACC_TRY(set_lds(colnorm_glds_batch_kernel<T>, T::G_LDS_BYTES + 4 * T::BN * 8));
         lds_set = true;
     }
+    prof_begin(h0, PROF_GRAD);
     colnorm_glds_batch_kernel<T><<<dim3((unsigned)(h0->n / T::BN), act.n), NTHREADS, T::G_LDS_BYTES + 4 * T::BN * 8, b->stream>>>(
         b->table, act, h0->m, h0->ldv, h0->m, h0->n, gbase, ldg, sign);
+    prof_end(h0, PROF_GRAD);
     ACC_HIP(hipGetLastError());
     return ACCBPG_OK;
 }

@@ -572,7 +572,9 @@ extern "C" int accbpg_fw_update(accbpg_dopt* h, int64_t p, double xscale, double
     fw_rank1_kernel<<<(int)rb, FB, 0, h->stream>>>(h->fw_H, m, h->fw_hv, hcoef, hdiv, vp, h->dscal + 10);
     const int ns = fw_nsplit(h);
     dim3 vg((unsigned)((n + VG_COLS - 1) / VG_COLS), (unsigned)ns);
+    prof_begin(h, PROF_FWV);
     fw_vgemv_partial_kernel<<<vg, FB, 0, h->stream>>>(h->V, h->ldv, m, n, h->fw_hv, ns, h->vws, h->vec_ok);
+    prof_end(h, PROF_FWV);
     // w update fused with stage 1 of the next probe (same support threshold as the last probe call)
     int64_t wb = (n + FB - 1) / FB;
     if (wb > 512) wb = 512;                                     // 2*512 probe records behind Hv / vp

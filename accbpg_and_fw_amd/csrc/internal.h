@@ -57,7 +57,7 @@ struct TileRC {
 
 // A batch of same-shaped instances evaluated by ONE launch per kernel family (blockIdx.y = position among the
 // active instances): the per-instance pointers live in a device table, the active set travels as a kernel argument.
-constexpr int BATCH_MAX = 64;
+constexpr int BATCH_MAX = ACCBPG_BATCH_MAX;
 struct BatchAct {
     int n = 0;
     int idx[BATCH_MAX] = {};
@@ -98,7 +98,7 @@ constexpr int FLAG_ABORT = 4;   // the one-launch Cholesky gave up a wait (co-re
 constexpr int STATUS_DOUBLES = 20;   // 16 scalars + 8 status flags, copied to the host in one piece
 constexpr int ACCBPG_RETRY = 100;    // internal: redo the evaluation with the launch-per-column Cholesky
 
-enum ProfKind { PROF_GRAM = 0, PROF_CHOL = 1, PROF_TRTRI = 2, PROF_GRAD = 3, PROF_GRAMFIX = 4, PROF_COUNT = 5 };
+enum ProfKind { PROF_GRAM = 0, PROF_CHOL = 1, PROF_TRTRI = 2, PROF_GRAD = 3, PROF_GRAMFIX = 4, PROF_FWV = 5, PROF_COUNT = 6 };
 
 struct ProfSlot {
     std::vector<hipEvent_t> ev;   // pairs (start, stop)
@@ -248,6 +248,7 @@ int launch_test_gemm(const double* A, int64_t lda, const double* B, int64_t ldb,
                      int64_t M, int64_t N, int64_t K, int b_kmajor, double alpha, double beta, int config,
                      hipStream_t s);
 int build_plans(accbpg_dopt* h);
+void set_plan_flags(int flags);
 int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, double* ms_out);
 int mfma_peak(int iters, double* tflops, hipStream_t s);
 int pipe_probe(int iters, int mode, double* ms_out, hipStream_t s);

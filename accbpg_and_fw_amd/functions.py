@@ -417,7 +417,7 @@ class DOptimalObj(RSmoothFunction):
 
     def profile_read(self):
         out = {}
-        for idx, name in enumerate(["gram", "cholesky", "trtri", "grad", "gram_fixup"]):
+        for idx, name in enumerate(["gram", "cholesky", "trtri", "grad", "gram_fixup", "fw_vpass"]):
             tot, num = 0.0, 0
             for h in self._handles():
                 ms, cnt = C.c_double(0.0), C.c_int64(0)

@@ -345,7 +345,7 @@ def main():
         from accbpg_and_fw_amd.batched import ABPG_batch_steps, ABPG_gain_batch_steps, DOptimalBatch
         lockstep = DOptimalBatch([f.V_dev] + [make_instance(m, n, 1 + idx, device) for idx in mine[1:]])
         objs = [lockstep]
-        prof_objs = []
+        prof_objs = [lockstep]
         if args.workload == "abpg":
             gen = ABPG_batch_steps(lockstep, acc.BurgEntropySimplex(), 1.0, x0, 2, horizon, overlap=overlap)
         else:
@@ -414,9 +414,20 @@ def main():
 
     # ---- the driver-timed region: W warm-up steps, then exactly K steps
     advance(args.warmup)
-    for o in prof_objs:
-        o.profile(True)
+    is_fw = args.workload.startswith("fw")
+    if not is_fw:
+        for o in prof_objs:
+            o.profile(True)
     elapsed, calls = timed(args.steps)
+    if is_fw:
+        # Frank-Wolfe steps take ~0.1 ms: the event pair around the pass over V would be a measurable share of the
+        # driver-timed region, so the kernel is timed over the SAME NUMBER of further steps of the same run instead
+        fw_gen_extra = fw_generator(f, x0, args.workload == "fw_away", args.steps + 1, args.logdet_refresh, args.logdet_ring)
+        for o in prof_objs:
+            o.profile(True)
+        for _ in range(args.steps):
+            next(fw_gen_extra)
+        torch.cuda.synchronize()
     prof = {}
     for o in prof_objs:
         for k, v in o.profile_read().items():
@@ -550,7 +561,8 @@ def main():
             # dominant kernel: Gram stream-K.  Algorithmic flops per launch = m^2 * n_local (SURVEY 8(d):
             # the SYRK share of 2 m^2 n + m^3/3 + 2 m n).
             n_local = (f.hi - f.lo) if shard else n
-            flops = float(m) * m * n_local
+            per_launch = ipg if lockstep is not None else 1    # a lock-step launch covers every instance of the GPU
+            flops = float(m) * m * n_local * per_launch
             achieved = flops / (gram_ms / gram_cnt * 1e-3) * 1e-12 if gram_cnt else None
             traffic = None
             try:        # HBM bytes per launch from this round's PMC passes (same workload only)
@@ -564,8 +576,11 @@ def main():
                                "frac": achieved / PEAK_FP64_MFMA_TFLOPS if achieved else None, "traffic": traffic,
                                "traffic_source": os.path.relpath(TRAFFIC_FILE, ROOT) if traffic else None,
                                "avg_launch_ms": gram_ms / gram_cnt if gram_cnt else None, "launches": gram_cnt,
+                               "instances_per_launch": per_launch,
                                "timing": "HIP events around every launch on the launching stream, inside the timed region"
-                                         + (" (concurrent instances share the chip)" if ipg > 1 else "")}
+                                         + (" (one launch covers the %d instances of the lock-step batch; all of them "
+                                            "active in this window)" % ipg if lockstep is not None else
+                                            (" (concurrent instances share the chip)" if ipg > 1 else ""))}
             if grad_cnt:
                 ga = flops / (grad_ms / grad_cnt * 1e-3) * 1e-12
                 out["roofline_grad_kernel"] = {"bound": "mfma", "kernel": "colnorm_glds_kernel (triangular product + column norms)",
@@ -583,9 +598,23 @@ def main():
             # Frank-Wolfe step: HBM bound, algorithmic bytes 8 m n + 24 m^2 + 48 n per step
             bytes_step = 8.0 * m * n + 24.0 * m * m + 48.0 * n
             achieved = bytes_step / (elapsed / args.steps) * 1e-9
-            out["roofline"] = {"bound": "hbm", "kernel": "fw step (whole step, host-timed)", "achieved": achieved,
-                               "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-                               "traffic": None}
+            vp_ms, vp_cnt = prof.get("fw_vpass", (0.0, 0))
+            vach = 8.0 * m * n / (vp_ms / vp_cnt * 1e-3) * 1e-9 if vp_cnt else None
+            # dominant kernel: the pass over V (u = Hv^T V), algorithmic 8 m n bytes per launch
+            out["roofline"] = {"bound": "hbm", "kernel": "fw_vgemv_partial_kernel (the pass over V of one step)",
+                               "achieved": vach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": vach / PEAK_HBM_GBS if vach else None, "traffic": None,
+                               "avg_launch_ms": vp_ms / vp_cnt if vp_cnt else None, "launches": vp_cnt,
+                               "timing": "HIP events around the launch on its stream, over %d further steps of the same "
+                                         "solver right behind the driver-timed region (the event pair would be a "
+                                         "measurable share of a 0.1-0.2 ms step)" % args.steps}
+            out["whole_step"] = {"algorithmic_bytes": bytes_step, "achieved_GBps": achieved,
+                                 "frac_of_hbm_peak": achieved / PEAK_HBM_GBS,
+                                 "note": "8 m n + 24 m^2 + 48 n bytes (SURVEY 8(d)) over the host-timed step"}
+            if args.workload == "fw_away":
+                from accbpg_and_fw_amd import D_opt_alg as DA
+                out["config"]["logdet_refresh"] = DA.LOGDET_REFRESH_DEFAULT if args.logdet_refresh is None else args.logdet_refresh
+                out["config"]["logdet_ring"] = DA.LOGDET_RING_DEFAULT if args.logdet_ring is None else args.logdet_ring
         # measured fp64 MFMA peak on this device
         import ctypes as C
         from accbpg_and_fw_amd import _lib

@@ -127,8 +127,10 @@ int accbpg_dopt_eval_gram(accbpg_dopt* h, const double* gram_dev, int flag, doub
  * that of accbpg_dopt_func_grad / accbpg_burg_simplex_div_prox / accbpg_ls_terms / accbpg_vec_axpby on the handle
  * accbpg_dopt_batch_instance(b, i) -- bit for bit -- so a batch and a loop over its instances give identical results.
  * The per-instance decisions (stopping, line search) stay with the caller, who re-issues the instances that need
- * another pass.  Shapes outside the fused path (m not a multiple of 256, n not a multiple of 128, unaligned rows, more
- * than 32 instances) are evaluated instance by instance behind the same interface. */
+ * another pass.  Shapes outside the fused path (m not a multiple of 256, n not a multiple of 128, unaligned rows) are
+ * evaluated instance by instance behind the same interface.  A batch holds at most ACCBPG_BATCH_MAX instances;
+ * accbpg_dopt_batch_create returns ACCBPG_ERR_ARG for more (split them over several batches). */
+#define ACCBPG_BATCH_MAX 64
 typedef struct accbpg_dopt_batch accbpg_dopt_batch;
 
 /* V_dev_host: HOST array of K device pointers (m x n row-major matrices, leading dimension ldv, borrowed). */
@@ -309,7 +311,8 @@ int accbpg_vec_dot(const double* x_dev, const double* y_dev, int64_t n, double* 
  * of the named kernel family on the handle's stream between reset and read.
  * which: 0 = Gram stream-K kernel (weighted SYRK), 1 = Cholesky (all its launches), 2 = triangular
  * inverse (all its launches), 3 = gradient kernel (triangular product + column norms), 4 = Gram
- * fix-up kernel.  enable != 0 turns event recording on. */
+ * fix-up kernel, 5 = the pass over V of a Frank-Wolfe update (u = Hv^T V).  enable != 0 turns event recording on.
+ * For a batch (accbpg_dopt_batch_*) the batched launches are accounted on the handle accbpg_dopt_batch_instance(b, 0). */
 int accbpg_dopt_profile_enable(accbpg_dopt* h, int enable);
 int accbpg_dopt_profile_read(accbpg_dopt* h, int which, double* total_ms_host, int64_t* launches_host);
 int accbpg_dopt_profile_reset(accbpg_dopt* h);
@@ -340,10 +343,15 @@ int accbpg_debug_gram_variant(accbpg_dopt* h, const double* x_dev, int variant, 
  * workgroup on every compute unit (m > 1408 on 256 CUs), one launch below that. */
 int accbpg_dopt_factor_in_small_launches(accbpg_dopt* h, int on);
 
+/* Development switch for handles created AFTER the call: bit 0 = plain stream-K ranges of the Gram kernel also where the
+ * tile list is longer than the grid (m >= 4096), instead of whole tiles per workgroup (A/B measurements). */
+int accbpg_debug_plan_flags(int flags);
+
 /* Timing ablation bits for the Cholesky step kernel (development aid; 0 = product behaviour):
  * 1 skip the diagonal-block factorisation, 2 skip the panel solve, 4 skip the MFMA products; 8, 16, 32 switch
  * off the row solves / MFMA updates / 16x16 factor inside the 64x64 factorisation.  256 / 512 select the
- * register-staged / direct-to-LDS Gram and gradient kernels.  2048 sets the scheme of the factorisation
+ * register-staged / direct-to-LDS Gram and gradient kernels; bits 30..31 select the schedule of the direct-to-LDS
+ * kernels (0 product, 1 / 2 development variants; bit-identical results).  2048 sets the scheme of the factorisation
  * (results agree to rounding): bits 12..23 = number of 64-wide block columns from which the two-level scheme
  * runs (default 64), bits 24..29 = block columns per outer panel (default 8; 0 leaves it). */
 int accbpg_debug_chol_variant(accbpg_dopt* h, int bits);

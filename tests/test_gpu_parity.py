@@ -1042,6 +1042,22 @@ def test_lockstep_abpg_gain_matches_sequential(acc, shape, K, opts):
     assert len(patterns) > 1 or K == 1                          # the instances did not all search alike
 
 
+def test_batch_size_limit_is_a_clean_error(acc):
+    """A batch holds at most ACCBPG_BATCH_MAX = 64 instances (the active set travels as a fixed-size kernel argument):
+    one more is refused at creation with ACCBPG_ERR_ARG -> ValueError, 64 are accepted and evaluate."""
+    from accbpg_and_fw_amd.batched import DOptimalBatch
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    Vs = [torch.randn(64, 256, dtype=torch.float64, device="cuda", generator=gen) for _ in range(65)]
+    with pytest.raises(ValueError, match="at most"):
+        DOptimalBatch(Vs)
+    b = DOptimalBatch(Vs[:64])
+    x = torch.full((64, 256), 1.0 / 256, dtype=torch.float64, device="cuda")
+    fv, g = b.func_grad(x, flag=2)
+    assert np.all(np.isfinite(fv))
+    one = acc.DOptimalObj(Vs[63]).func_grad(x[63], 2)
+    assert fv[63] == pytest.approx(one[0], rel=1e-12)
+
+
 def test_batched_instances_match_sequential(acc):
     """Config-4 style batch: independent instances solved concurrently from host threads on
     separate streams give exactly the results of solving them one after the other."""

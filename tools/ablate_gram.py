@@ -1,18 +1,41 @@
-"""Time the Gram kernel ablation variants on the GPU (development aid)."""
-import ctypes as C, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-import accbpg_and_fw_amd as acc
-from accbpg_and_fw_amd import _lib
-m, n = 2048, 32768
-V = torch.randn(m, n, dtype=torch.float64, device="cuda")
-f = acc.DOptimalObj(V)
-x = torch.full((n,), 1.0 / n, dtype=torch.float64, device="cuda")
-lib = _lib.load()
-names = {10: "glds full", 11: "glds no loads", 12: "glds no wait+barrier", 13: "glds no loads no barrier",
-         14: "glds no fragment reads", 15: "glds barrier w/o vmcnt wait", 16: "glds MFMA only", 17: "glds half of the fragment reads"}
-for rep in range(2):
-    for var in [10, 11, 12, 13, 14, 15, 16, 17]:
-        ms = C.c_double(0.0)
-        rc = lib.accbpg_debug_gram_variant(f._h, C.c_void_p(x.data_ptr()), var, 10, C.byref(ms))
-        print("variant %d (%-24s) rc=%d  %.3f ms" % (var, names[var], rc, ms.value), flush=True)
+"""What a launch of the Gram kernel is made of (development aid): timing ablations of the production loop and of the
+dealt-out schedule through accbpg_debug_gram_variant (wrong results except the first two), interleaved rounds."""
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CODES = {10: "block schedule (production in round 2)", 19: "dealt-out schedule B", 20: "B, no loads in the loop",
+         21: "B, no wait + barrier", 22: "B, no fragment reads", 23: "B, barrier without the vmcnt wait",
+         24: "B, MFMA only", 25: "B, loads only", 26: "B, barrier only", 27: "B, reads only"}
+
+
+def main():
+    import torch
+    import accbpg_and_fw_amd as acc
+    from accbpg_and_fw_amd import _lib
+    from accbpg_and_fw_amd.functions import _ptr
+    lib = _lib.load()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    V = torch.randn(2048, 32768, dtype=torch.float64, device="cuda", generator=gen)
+    x = torch.rand(32768, dtype=torch.float64, device="cuda", generator=gen) + 0.05
+    x /= x.sum()
+    f = acc.DOptimalObj(V)
+    ms = C.c_double(0.0)
+    out = {c: [] for c in CODES}
+    for rnd in range(3):
+        for c in CODES:
+            _lib.check(lib.accbpg_debug_gram_variant(f._h, _ptr(x), c, 20, C.byref(ms)), "variant %d" % c)
+            out[c].append(ms.value)
+    res = {CODES[c]: min(v) for c, v in out.items()}
+    print(json.dumps(res, indent=1))
+    if len(sys.argv) > 1:
+        with open(sys.argv[1], "w") as fh:
+            json.dump(res, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
