@@ -54,6 +54,7 @@ _SIGS = {
     "accbpg_dopt_batch_set_stream": (C.c_int, [_P, _P]),
     "accbpg_dopt_batch_size": (C.c_int, [_P]),
     "accbpg_dopt_batch_is_fused": (C.c_int, [_P]),
+    "accbpg_dopt_batch_chunk": (C.c_int, [_P]),
     "accbpg_dopt_batch_instance": (_P, [_P, C.c_int]),
     "accbpg_dopt_batch_func_grad": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double), _P,
                                               C.c_int64, C.POINTER(C.c_int)]),

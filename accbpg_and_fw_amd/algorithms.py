@@ -49,7 +49,9 @@ def _value_begin(f, x, combo):
 
 def _can_speculate(f, x, checkdiv):
     """Gradient evaluations may be started ahead of the line-search decision on this package's D-optimal objective
-    (DOptimalObj.speculate, default) when it evaluates directly, on the device, with the side stream in use."""
+    when the caller has switched that on (DOptimalObj.speculate -- opt-in: measured slower at (2048,32768), 47.7
+    against 50.5 it/s, and 3 % faster at (512,8192)) and it evaluates directly, on the device, with the side stream
+    in use."""
     return (not checkdiv) and (not _lin(f)) and getattr(f, "_spec", False) and getattr(f, "_overlap", False) \
         and not getattr(f, "_prof", False) and hasattr(f, "grad_async") and isinstance(x, torch.Tensor) and x.is_cuda
 

@@ -46,6 +46,7 @@ class DOptimalBatch:
         _lib.check(rc, "accbpg_dopt_batch_create")
         self._h = h
         self.fused = bool(self._lib.accbpg_dopt_batch_is_fused(h))
+        self.chunk = int(self._lib.accbpg_dopt_batch_chunk(h))      # instances one launch covers
         self.calls = {"value": 0, "grad": 0}        # per instance-evaluation, as DOptimalObj counts them
         self._views = {}
 

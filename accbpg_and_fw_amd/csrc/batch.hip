@@ -25,8 +25,9 @@ static int batch_init(accbpg_dopt_batch* b, const double* const* V_host, int K, 
     ACC_HIP(hipMalloc(&b->dscal_all, sizeof(double) * 24 * (size_t)K));
     ACC_HIP(hipMemset(b->dscal_all, 0, sizeof(double) * 24 * (size_t)K));
     ACC_HIP(hipHostMalloc(&b->hpin, sizeof(double) * 24 * (size_t)K, hipHostMallocDefault));
-    // instances that share a launch: as many as have their one-launch factorisations resident together
-    // (T(T+1)/2 - (T-1) workgroups each, two per CU)
+    // instances that share a launch: as many as have their one-launch factorisations resident together.  The first
+    // guess (T(T+1)/2 - (T-1) workgroups each, two per CU) sizes the per-instance Gram grids; it is replaced below by
+    // what the plan of instance 0 says (its grid, and the slots the occupancy query reports).
     const int T = (int)((m + NB - 1) / NB);
     const int per_inst = std::max(1, T * (T + 1) / 2 - (T - 1));
     b->chunk = std::max(1, std::min(K, (2 * prop.multiProcessorCount) / per_inst));
@@ -40,6 +41,8 @@ static int batch_init(accbpg_dopt_batch* b, const double* const* V_host, int K, 
         ACC_TRY(dopt_init(h));
     }
     accbpg_dopt* h0 = b->inst[0];
+    if (h0->chol_tiles_ok && h0->chol_tiles_grid > 0)
+        b->chunk = std::max(1, std::min(b->chunk, h0->chol_slots / h0->chol_tiles_grid));
     // one launch per kernel family needs: the interior big-tile path, the one-launch Cholesky for every instance at
     // once, identical plans (same shape and alignment give identical plans)
     bool fast = h0->big && h0->use_glds && (m % 256 == 0) && (n % 128 == 0) && h0->chol_tiles_ok && K <= BATCH_MAX;
@@ -120,6 +123,7 @@ extern "C" int accbpg_dopt_batch_create(const double* const* V_dev_host, int K, 
 
 extern "C" int accbpg_dopt_batch_size(accbpg_dopt_batch* b) { return b ? b->K : 0; }
 extern "C" int accbpg_dopt_batch_is_fused(accbpg_dopt_batch* b) { return (b && b->fast) ? 1 : 0; }
+extern "C" int accbpg_dopt_batch_chunk(accbpg_dopt_batch* b) { return b ? (b->fast ? std::min(b->chunk, b->K) : 1) : 0; }
 
 extern "C" accbpg_dopt* accbpg_dopt_batch_instance(accbpg_dopt_batch* b, int i) {
     if (!b || i < 0 || i >= b->K) return nullptr;
@@ -199,6 +203,7 @@ extern "C" int accbpg_dopt_batch_func_grad_end(accbpg_dopt_batch* b, double* f_h
         }
         // the one-launch Cholesky gave up a wait: evaluate instance by instance with the launch-per-column kernels
         b->fast = false;
+        note_tiles_fallback("accbpg_dopt_batch_func_grad");
         for (accbpg_dopt* h : b->inst) h->chol_tiles_off = true;
     }
     for (int a = 0; a < act.n; ++a) {

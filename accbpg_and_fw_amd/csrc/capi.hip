@@ -16,6 +16,17 @@ void set_last_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// the one-launch Cholesky gave up a wait and the handle stays on the launch-per-column kernels from here on: results are
+// the same, every factorisation is slower -- worth one line on stderr (once per process)
+void note_tiles_fallback(const char* where) {
+    static bool said = false;
+    if (said) return;
+    said = true;
+    fprintf(stderr, "libaccbpg_hip: %s: the one-launch Cholesky abandoned a wait (another process on this GPU, or fewer "
+                    "workgroups resident than the occupancy query promised); this handle factors with one launch per block "
+                    "column from now on\n", where);
+}
+
 static int read_status(accbpg_dopt* h) {
     ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * STATUS_DOUBLES, hipMemcpyDeviceToHost, h->stream));   // scalars + flags
     ACC_HIP(hipStreamSynchronize(h->stream));
@@ -125,6 +136,7 @@ extern "C" int accbpg_dopt_factor(accbpg_dopt* h, const double* gram_dev, double
             return ACCBPG_ERR_HIP;
         }
         h->chol_tiles_off = true;
+        note_tiles_fallback("accbpg_dopt_factor");
         return accbpg_dopt_factor(h, gram_dev, f_host);
     }
     if (fl[FLAG_NOT_PD]) {
@@ -193,6 +205,7 @@ extern "C" int accbpg_dopt_func_grad_end(accbpg_dopt* h, double* f_host) {
         // the one-launch factorisation gave up a wait (its workgroups were not all resident in time, e.g. another
         // process shares the GPU): redo this evaluation with one launch per block column, and stay with that
         h->chol_tiles_off = true;
+        note_tiles_fallback("accbpg_dopt_func_grad");
         ACC_TRY(accbpg_dopt_func_grad_begin(h, h->last_x, h->last_flag, h->last_g));
         return accbpg_dopt_func_grad_end(h, f_host);
     }
@@ -310,6 +323,7 @@ extern "C" int accbpg_dopt_eval_gram(accbpg_dopt* h, const double* gram_dev, int
             return ACCBPG_ERR_HIP;
         }
         h->chol_tiles_off = true;
+        note_tiles_fallback("accbpg_dopt_eval_gram");
         return accbpg_dopt_eval_gram(h, gram_dev, flag, f_host, g_dev);
     }
     if (fl[FLAG_NOT_PD]) {

@@ -367,6 +367,7 @@ __device__ __forceinline__ void gram_streamk_glds_body(
     }
 }
 
+constexpr int GRAM_GV = 96;     // schedule of the production Gram kernel: dealt out (32), placement B (64)
 template <class T, int GV = 0>
 __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_glds_kernel(
     const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n, const double* __restrict__ x,
@@ -385,8 +386,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_glds_batch_kernel(
     int64_t ldg) {
     const int inst = act.idx[blockIdx.y];
     const BatchInst bi = bt[inst];
-    gram_streamk_glds_body<T, 0>(bi.V, ldv, m, n, xbase + (int64_t)inst * ldx, tiles, wg_ranges, kiters, nslot, bi.slabs,
-                                 bi.gram, ldg);
+    gram_streamk_glds_body<T, GRAM_GV>(bi.V, ldv, m, n, xbase + (int64_t)inst * ldx, tiles, wg_ranges, kiters, nslot, bi.slabs,
+                                       bi.gram, ldg);
 }
 
 // grid = ntiles * 2 * T::MI * FIX_PJ: workgroup (entry, half, part, jq) sums column-fragment group jq of
@@ -2442,7 +2443,8 @@ int build_plans(accbpg_dopt* h) {
         int per_cu = 0;
         ACC_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chol_tiles_kernel, NTHREADS, CT_LDS_BYTES));
         h->chol_tiles_grid = (int)jobs.size();
-        h->chol_tiles_ok = per_cu >= 1 && (int64_t)jobs.size() <= (int64_t)std::min(per_cu, 2) * h->num_cu;
+        h->chol_slots = std::min(per_cu, 2) * h->num_cu;         // workgroups of this kernel the chip holds at once
+        h->chol_tiles_ok = per_cu >= 1 && (int64_t)jobs.size() <= (int64_t)h->chol_slots;
         if (h->chol_tiles_ok) {
             ACC_HIP(hipMalloc(&h->chol_jobs, sizeof(CholJob) * jobs.size()));
             ACC_HIP(hipMemcpy(h->chol_jobs, jobs.data(), sizeof(CholJob) * jobs.size(), hipMemcpyHostToDevice));
@@ -2482,14 +2484,16 @@ template <class T>
 static void gram_launch_t(accbpg_dopt* h, const double* x, double* gram) {
     prof_begin(h, PROF_GRAM);
     if constexpr (!T::EDGE && T::BM == 256) {
+        // production: the dealt-out schedule, placement B (GRAM_GV); the development switch selects placement A (1) or
+        // the block schedule of round 2 (3) -- all three give bit-identical results
         if ((h->use_glds || h->has_duals) && h->kern_variant == 1)
             gram_streamk_glds_kernel<T, 32><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
                 h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m);
-        else if ((h->use_glds || h->has_duals) && h->kern_variant == 2)
-            gram_streamk_glds_kernel<T, 96><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
+        else if ((h->use_glds || h->has_duals) && h->kern_variant == 3)
+            gram_streamk_glds_kernel<T, 0><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
                 h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m);
         else if (h->use_glds || h->has_duals)
-            gram_streamk_glds_kernel<T><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
+            gram_streamk_glds_kernel<T, GRAM_GV><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
                 h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m);
         else
             gram_streamk_kernel<T><<<h->gram_grid, NTHREADS, T::LDS_BYTES, h->stream>>>(
@@ -2665,7 +2669,7 @@ static int launch_chol_tiles(accbpg_dopt* h, const double* src, double* A, doubl
     {
         int gmax = h->chol_tiles_grid;
         for (int i = 0; i < TILES_RING; ++i) gmax = std::max(gmax, ring.grid[i]);
-        int together = (2 * h->num_cu) / std::max(1, gmax);
+        int together = std::max(1, h->chol_slots) / std::max(1, gmax);
         if (together > TILES_RING - 1) together = TILES_RING - 1;   // (so that the waits of successive launches chain)
         if (together < 1) together = 1;
         for (long long back = together; back <= TILES_RING && back <= ring.issued; ++back) {
@@ -2823,7 +2827,7 @@ int launch_cholesky_batch(accbpg_dopt_batch* b, const BatchAct& act, bool with_i
     {
         int gmax = grid_all;
         for (int i = 0; i < TILES_RING; ++i) gmax = std::max(gmax, ring.grid[i]);
-        int together = (2 * h0->num_cu) / std::max(1, gmax);
+        int together = std::max(1, h0->chol_slots) / std::max(1, gmax);
         if (together > TILES_RING - 1) together = TILES_RING - 1;
         if (together < 1) together = 1;
         for (long long back = together; back <= TILES_RING && back <= ring.issued; ++back) {

@@ -452,6 +452,7 @@ static int fw_slot_collect(accbpg_dopt::FwSlot& sl, double* logdet) {
         // the one-launch factorisation gave up a wait: the snapshot (in Gbuf) is intact, factor it with a launch per
         // block column, and keep this slot on those
         a->chol_tiles_off = true;
+        note_tiles_fallback("accbpg_fw_probe_step (side factorisation)");
         ACC_TRY(fw_slot_factor(sl, a->Gbuf));
         ACC_HIP(hipEventSynchronize(a->ev_done));
     }

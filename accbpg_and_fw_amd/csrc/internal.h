@@ -10,6 +10,7 @@
 namespace accbpg {
 
 void set_last_error(const char* fmt, ...);
+void note_tiles_fallback(const char* where);
 
 #define ACC_HIP(call)                                                                         \
     do {                                                                                      \
@@ -180,6 +181,7 @@ struct accbpg_dopt {
     int chol_stall_test = 0;        // debug: make the launch time out
     long long chol_spin_limit = 20000000;   // 0.2 s of the 100 MHz wall clock
     int chol_tiles_grid = 0;
+    int chol_slots = 0;             // workgroups of the one-launch kernel the chip holds at once (occupancy query x CUs, at most 2 per CU)
     void* chol_jobs = nullptr;      // CholJob[chol_tiles_grid]
     int* chol_ready = nullptr;      // T*T hand-off flags
     double* chol_aux = nullptr;     // T * CT_AUX doubles

@@ -30,6 +30,7 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    char why[256] = "";      // what dlopen said about the last name tried
 };
 
 Rccl* rccl() {
@@ -40,6 +41,8 @@ Rccl* rccl() {
         for (const char* nm : names) {
             r.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
             if (r.lib) break;
+            const char* why = dlerror();                        // (valid right behind the failed dlopen only)
+            snprintf(r.why, sizeof(r.why), "%s", why ? why : "dlopen failed without a message");
         }
         if (!r.lib) return;
         bool all = true;
@@ -60,7 +63,7 @@ Rccl* rccl() {
 int need_rccl(Rccl** out) {
     Rccl* r = rccl();
     if (!r->ok) {
-        set_last_error("RCCL (librccl.so.1) could not be opened: %s", r->lib ? "a symbol is missing" : dlerror());
+        set_last_error("RCCL (librccl.so.1) could not be opened: %s", r->lib ? "a symbol is missing" : r->why);
         return ACCBPG_ERR_HIP;
     }
     *out = r;

@@ -41,7 +41,7 @@ if ROOT not in sys.path:
 
 PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X vendor figure (fp64 matrix); confirmed on the box by accbpg_mfma_f64_peak
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
 
 CONFIGS = {      # BASELINE.json configs -> defaults of the switches below
     2: dict(workload="abpg_gain", m=2048, n=32768, mode="instances", instances_per_gpu=1),
@@ -415,18 +415,26 @@ def main():
     # ---- the driver-timed region: W warm-up steps, then exactly K steps
     advance(args.warmup)
     is_fw = args.workload.startswith("fw")
-    if not is_fw:
+    # Kernel timing inside the driver-timed region where a step is long (one instance of the BPG family: two event
+    # records per launch against milliseconds of kernels).  Where a step is short -- Frank-Wolfe (~0.1-0.2 ms), the
+    # lock-step batch (its value evaluations then also leave the side stream) -- the kernels are timed over the SAME
+    # NUMBER of further steps of the same run right behind the region instead, and the region stays as users run it.
+    prof_after = is_fw or lockstep is not None
+    if not prof_after:
         for o in prof_objs:
             o.profile(True)
     elapsed, calls = timed(args.steps)
-    if is_fw:
-        # Frank-Wolfe steps take ~0.1 ms: the event pair around the pass over V would be a measurable share of the
-        # driver-timed region, so the kernel is timed over the SAME NUMBER of further steps of the same run instead
-        fw_gen_extra = fw_generator(f, x0, args.workload == "fw_away", args.steps + 1, args.logdet_refresh, args.logdet_ring)
+    if prof_after:
+        if is_fw:
+            fw_gen_extra = fw_generator(f, x0, args.workload == "fw_away", args.steps + 1, args.logdet_refresh,
+                                        args.logdet_ring)
+            more = lambda: next(fw_gen_extra)
+        else:
+            more = lambda: advance(1)
         for o in prof_objs:
             o.profile(True)
         for _ in range(args.steps):
-            next(fw_gen_extra)
+            more()
         torch.cuda.synchronize()
     prof = {}
     for o in prof_objs:
@@ -541,7 +549,8 @@ def main():
                        "seeds": "1..%d" % (world * ipg), "collectives": backend,
                        "window": "transient: iterations %d..%d from x0 = 1/n" % (args.warmup, total - 1),
                        "oracle_calls_per_step": calls,
-                       "value_overlap": "off in the timed region (kernel timing on), on in steady_state and overlap_variant"
+                       "value_overlap": ("on" if lockstep is not None else
+                                         "off in the timed region (kernel timing on), on in steady_state and overlap_variant")
                                         if overlap else "off",
                        "linear_gram": bool(args.linear_gram)},
         }
@@ -561,7 +570,12 @@ def main():
             # dominant kernel: Gram stream-K.  Algorithmic flops per launch = m^2 * n_local (SURVEY 8(d):
             # the SYRK share of 2 m^2 n + m^3/3 + 2 m n).
             n_local = (f.hi - f.lo) if shard else n
-            per_launch = ipg if lockstep is not None else 1    # a lock-step launch covers every instance of the GPU
+            # a lock-step launch covers every instance of the GPU, or `chunk` of them where their one-launch
+            # factorisations do not fit the chip together (64 instances: chunks of 15, the last one smaller -- the
+            # average launch then covers ipg / ceil(ipg / chunk) instances)
+            per_launch = 1
+            if lockstep is not None:
+                per_launch = ipg / float(-(-ipg // max(1, lockstep.chunk)))
             flops = float(m) * m * n_local * per_launch
             achieved = flops / (gram_ms / gram_cnt * 1e-3) * 1e-12 if gram_cnt else None
             traffic = None
@@ -574,12 +588,17 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": "gram_streamk_glds_kernel (weighted Gram matrix, stream-K)",
                                "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": achieved / PEAK_FP64_MFMA_TFLOPS if achieved else None, "traffic": traffic,
-                               "traffic_source": os.path.relpath(TRAFFIC_FILE, ROOT) if traffic else None,
+                               "traffic_source": ("replayed from %s: HBM bytes per launch counted by separate rocprofv3 --pmc "
+                                                  "passes of this command (a counter pass cannot run inside the timed "
+                                                  "process), not in this run" % os.path.relpath(TRAFFIC_FILE, ROOT))
+                                                 if traffic else None,
                                "avg_launch_ms": gram_ms / gram_cnt if gram_cnt else None, "launches": gram_cnt,
                                "instances_per_launch": per_launch,
-                               "timing": "HIP events around every launch on the launching stream, inside the timed region"
-                                         + (" (one launch covers the %d instances of the lock-step batch; all of them "
-                                            "active in this window)" % ipg if lockstep is not None else
+                               "timing": ("HIP events around every launch on the launching stream, "
+                                          + ("over %d further steps of the same run right behind the timed region"
+                                             % args.steps if lockstep is not None else "inside the timed region"))
+                                         + (" (a launch covers %.1f instances of the lock-step batch on average; all of them "
+                                            "active in this window)" % per_launch if lockstep is not None else
                                             (" (concurrent instances share the chip)" if ipg > 1 else ""))}
             if grad_cnt:
                 ga = flops / (grad_ms / grad_cnt * 1e-3) * 1e-12

@@ -100,7 +100,11 @@ int accbpg_vec_count_bad(const double* x_dev, int64_t n, double* count_dev, void
  * accbpg_dopt_shard_func_grad evaluates f(x) = -log det(V diag(x) V^T) (accbpg/functions.py:40-60) at the whole
  * length-n device vector x, which every rank holds: one all-reduce of the packed Gram triangle (+ the x >= 0
  * violation count) and, for flags 1 and 2, one all-gather of the gradient slices; g_dev receives the whole
- * gradient on every rank.  Return codes as accbpg_dopt_func_grad, the same on every rank. */
+ * gradient on every rank.  Return codes as accbpg_dopt_func_grad, the same on every rank -- EXCEPT ACCBPG_ERR_HIP: a HIP
+ * or RCCL failure on one rank returns on that rank before the collective the other ranks are entering, and they stay in
+ * it (RCCL has no timeout of its own); a caller that survives ACCBPG_ERR_HIP must tear the job down.  At world > 1 these
+ * entry points have not run on hardware yet (one GPU per box in the builds so far): the message layout and the assembly
+ * of unequal slices are covered with two gloo ranks on the CPU and with one rank on a GPU. */
 #define ACCBPG_SHARD_ID_BYTES 128
 typedef struct accbpg_dopt_shard accbpg_dopt_shard;
 int accbpg_dopt_shard_bounds(int64_t n, int world, int rank, int64_t* lo, int64_t* hi);
@@ -140,6 +144,8 @@ int accbpg_dopt_batch_destroy(accbpg_dopt_batch* b);
 int accbpg_dopt_batch_set_stream(accbpg_dopt_batch* b, void* stream);
 int accbpg_dopt_batch_size(accbpg_dopt_batch* b);
 int accbpg_dopt_batch_is_fused(accbpg_dopt_batch* b);          /* 1: one launch per kernel family covers the batch */
+int accbpg_dopt_batch_chunk(accbpg_dopt_batch* b);             /* instances one launch covers: all of them, unless their
+                                                                  one-launch factorisations do not fit the chip together */
 accbpg_dopt* accbpg_dopt_batch_instance(accbpg_dopt_batch* b, int i);   /* owned by the batch */
 
 /* DOptimalObj.func_grad (accbpg/functions.py:43-59) for the active instances.  f_host[i], status_host[i]
