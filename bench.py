@@ -84,6 +84,9 @@ def parse(argv=None):
     ap.add_argument("--linear-gram", action="store_true",
                     help="measure with Gram-matrix reuse through linearity switched on (extension); the "
                          "default run reports it separately as linear_gram_variant")
+    ap.add_argument("--memo-values", action="store_true",
+                    help="measure with DOptimalObj.memoize_values switched on (extension: F[k+1] = f(x) at the accepted "
+                         "line-search point is not evaluated a second time; identical results)")
     ap.add_argument("--no-variants", action="store_true",
                     help="skip the variant segments (profiling runs: the kernel trace then holds the headline "
                          "and steady-state regions only)")
@@ -321,13 +324,16 @@ def main():
         f.speculate(args.speculation)
     if args.linear_gram and not shard:
         f.linear_gram(True)
+    if args.memo_values and hasattr(f, "memoize_values"):
+        f.memoize_values(True)
     h = acc.BurgEntropySimplex()
     x0 = torch.full((n,), 1.0 / n, dtype=torch.float64, device=device)
     # (the steady-state window is 300 further iterations: only where an iteration takes tens of milliseconds)
     steady = (not args.no_steady) and args.workload in ("abpg_gain", "abpg", "bpg") and args.steady_iters > 0 \
         and float(m) * n <= 2.0 * 2048 * 32768
     total = args.warmup + args.steps
-    horizon = max(total, args.steady_start + args.steady_iters if steady else 0) + 2
+    # (the lock-step batch times its kernels over `steps` further steps behind the driver-timed region)
+    horizon = max(total + args.steps, args.steady_start + args.steady_iters + args.steps if steady else 0) + 2
 
     def make_gen(ff, hh, length):
         if args.workload == "abpg_gain":
@@ -461,7 +467,7 @@ def main():
                               "after the first ~20-30 iterations every iteration retries about once "
                               "(accbpg/algorithms.py:358-390)"}
 
-    variants_ok = (not args.no_variants) and (not args.linear_gram) and (not shard) and ipg == 1 \
+    variants_ok = (not args.no_variants) and (not args.linear_gram) and (not args.memo_values) and (not shard) and ipg == 1 \
         and args.workload in ("abpg_gain", "abpg")
 
     def variant_run():
@@ -552,7 +558,7 @@ def main():
                        "value_overlap": ("on" if lockstep is not None else
                                          "off in the timed region (kernel timing on), on in steady_state and overlap_variant")
                                         if overlap else "off",
-                       "linear_gram": bool(args.linear_gram)},
+                       "linear_gram": bool(args.linear_gram), "memo_values": bool(args.memo_values)},
         }
         if steady_out is not None:
             out["steady_state"] = steady_out

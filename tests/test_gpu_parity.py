@@ -1355,6 +1355,34 @@ def test_overlapped_value_evaluation_is_identical(acc, shape):
         f.value_wait(f.value_async(bad))
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_memoized_values_change_nothing(acc, overlap):
+    """DOptimalObj.memoize_values (opt-in): F[k+1] = f(x) at the accepted line-search point (accbpg/algorithms.py:347) is
+    answered from the value the accepting test computed at that very tensor (:387) instead of a second evaluation.  Every
+    trace is bit-identical to the run without it, one value evaluation per iteration is saved, and a tensor that was
+    modified in place or merely equal in content is evaluated afresh."""
+    f, h, L, x0 = acc.D_opt_design(300, 3000, randseed=4)
+    f.overlap_values(overlap)
+    a = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=80, verbose=False)
+    b0 = acc.BPG(f, h, L, x0, maxitrs=40, linesearch=True, verbose=False)
+    v0 = f.calls["value"]
+    f.memoize_values(True)
+    hits0 = f.value_hits
+    b = acc.ABPG_gain(f, h, L, x0, gamma=2, maxitrs=80, verbose=False)
+    hits = f.value_hits - hits0
+    b1 = acc.BPG(f, h, L, x0, maxitrs=40, linesearch=True, verbose=False)
+    for p, q in list(zip(a[:-1], b[:-1])) + list(zip(b0[:-1], b1[:-1])):
+        np.testing.assert_array_equal(p, q)
+    assert 70 <= hits <= 80                                     # every F[k], k >= 1, of the ABPG_gain run
+    xd = torch.from_numpy(x0).cuda()
+    v = f(xd)
+    assert f(xd) == v and f.value_hits > hits0 + hits           # the same object again: answered
+    xd.mul_(1.5)                                                # modified in place: evaluated afresh
+    assert f(xd) == pytest.approx(v - f.m * np.log(1.5), rel=1e-12)
+    assert f(xd.clone()) == f(xd)                               # equal content, another object: evaluated (same value)
+    f.memoize_values(False)
+
+
 @pytest.mark.parametrize("shape,opts", [((300, 3000), dict(gamma=2)), ((512, 8192), dict(gamma=2, G0=0.1)),
                                         ((256, 4096), dict(gamma=2, ls_inc=1.5, ls_dec=1.1, theta_eq=False, restart=True)),
                                         ((128, 1024), dict(gamma=1.5, G0=0.1, restart=True, restart_rule='f'))])
