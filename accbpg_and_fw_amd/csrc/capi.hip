@@ -95,6 +95,7 @@ extern "C" int accbpg_dopt_create(const double* V_dev, int64_t m, int64_t n, int
 
 extern "C" int accbpg_dopt_destroy(accbpg_dopt* h) {
     if (!h) return ACCBPG_OK;
+    hipFree(h->Vblk);
     hipFree(h->Lbuf); hipFree(h->Wbuf); hipFree(h->Tbuf); hipFree(h->slabs); hipFree(h->tiles); hipFree(h->wg_ranges); hipFree(h->gram_cstart); hipFree(h->gram_contrib);
     if (!h->dscal_ext) hipFree(h->dscal);
     hipFree(h->vws); hipFree(h->xbuf); hipFree(h->ops); hipFree(h->chol_op); hipFree(h->red); hipFree(h->Pbuf);

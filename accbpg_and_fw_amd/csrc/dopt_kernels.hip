@@ -150,7 +150,10 @@ __device__ __forceinline__ void gram_streamk_glds_body(
     const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n, const double* __restrict__ x,
     const TileRC* __restrict__ tiles, const int64_t* __restrict__ wg_ranges, int64_t kiters, int nslot,
     double* __restrict__ slabs,
-    double* __restrict__ G, int64_t ldg) {
+    double* __restrict__ G, int64_t ldg, int all_slabs) {
+    // all_slabs: every segment leaves its accumulators in a slab, also one that covers its whole tile -- the fix-up
+    // launch then ADDS the tile to G (a launch over one column block of V behind the first; the plan lists every
+    // segment as a contributor).  (Adding in this kernel's own epilogue cost it its register allocation.)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int NLD = T::G_NA + T::G_NB + 1;                  // loads per wave per stage
     T t;
@@ -356,7 +359,7 @@ __device__ __forceinline__ void gram_streamk_glds_body(
         }
         }
         asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // tail loads / reads retire before LDS is reused
-        if (sg.whole) {
+        if (sg.whole && !all_slabs) {
             t.store_C(G, ldg, row0, col0, m, m, 1.0, 0.0, true);
         } else {
             t.store_slab(slabs + ((int64_t)blockIdx.x * nslot + seg) * T::SLAB_DOUBLES);
@@ -373,8 +376,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_glds_kernel(
     const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n, const double* __restrict__ x,
     const TileRC* __restrict__ tiles, const int64_t* __restrict__ wg_ranges, int64_t kiters, int nslot,
     double* __restrict__ slabs,
-    double* __restrict__ G, int64_t ldg) {
-    gram_streamk_glds_body<T, GV>(V, ldv, m, n, x, tiles, wg_ranges, kiters, nslot, slabs, G, ldg);
+    double* __restrict__ G, int64_t ldg, int all_slabs) {
+    gram_streamk_glds_body<T, GV>(V, ldv, m, n, x, tiles, wg_ranges, kiters, nslot, slabs, G, ldg, all_slabs);
 }
 // The same kernel over the ACTIVE instances of a batch of same-shaped problems (blockIdx.y picks the instance;
 // the tile list and the stream-K ranges are shared, matrix / slabs / result come from the instance table, x from
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_glds_batch_kernel(
     const int inst = act.idx[blockIdx.y];
     const BatchInst bi = bt[inst];
     gram_streamk_glds_body<T, GRAM_GV>(bi.V, ldv, m, n, xbase + (int64_t)inst * ldx, tiles, wg_ranges, kiters, nslot, bi.slabs,
-                                       bi.gram, ldg);
+                                       bi.gram, ldg, 0);
 }
 
 // grid = ntiles * 2 * T::MI * FIX_PJ: workgroup (entry, half, part, jq) sums column-fragment group jq of
@@ -397,7 +400,7 @@ constexpr int FIX_PJ = 4;
 template <class T>
 __device__ __forceinline__ void gram_fixup_body(
     const TileRC* __restrict__ tiles, const int32_t* __restrict__ cstart, const int32_t* __restrict__ contrib,
-    int nslot, const double* __restrict__ slabs, double* __restrict__ G, int64_t ldg, int64_t m) {
+    int nslot, const double* __restrict__ slabs, double* __restrict__ G, int64_t ldg, int64_t m, double beta) {
     constexpr int JW = (T::NI + FIX_PJ - 1) / FIX_PJ;
     const int jq = blockIdx.x % FIX_PJ;
     const int b = blockIdx.x / FIX_PJ;
@@ -449,7 +452,10 @@ __device__ __forceinline__ void gram_fixup_body(
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = row0 + 16 * (part * T::WAVES_M + wm) + lq + 4 * r;
                 const int64_t col = col0 + wn * T::WN + 16 * j + lr;
-                if (row < m && col < m && col <= row) G[row * ldg + col] = a[jj][r];
+                if (row < m && col < m && col <= row) {
+                    double* gp = G + row * ldg + col;
+                    *gp = (beta != 0.0) ? a[jj][r] + beta * *gp : a[jj][r];
+                }
             }
         }
     }
@@ -458,15 +464,15 @@ __device__ __forceinline__ void gram_fixup_body(
 template <class T>
 __global__ __launch_bounds__(NTHREADS, 2) void gram_fixup_kernel(
     const TileRC* __restrict__ tiles, const int32_t* __restrict__ cstart, const int32_t* __restrict__ contrib,
-    int nslot, const double* __restrict__ slabs, double* __restrict__ G, int64_t ldg, int64_t m) {
-    gram_fixup_body<T>(tiles, cstart, contrib, nslot, slabs, G, ldg, m);
+    int nslot, const double* __restrict__ slabs, double* __restrict__ G, int64_t ldg, int64_t m, double beta) {
+    gram_fixup_body<T>(tiles, cstart, contrib, nslot, slabs, G, ldg, m, beta);
 }
 template <class T>
 __global__ __launch_bounds__(NTHREADS, 2) void gram_fixup_batch_kernel(
     const BatchInst* __restrict__ bt, BatchAct act, const TileRC* __restrict__ tiles, const int32_t* __restrict__ cstart,
     const int32_t* __restrict__ contrib, int nslot, int64_t ldg, int64_t m) {
     const BatchInst bi = bt[act.idx[blockIdx.y]];
-    gram_fixup_body<T>(tiles, cstart, contrib, nslot, bi.slabs, bi.gram, ldg, m);
+    gram_fixup_body<T>(tiles, cstart, contrib, nslot, bi.slabs, bi.gram, ldg, m, 0.0);
 }
 
 // =========================================================================================
@@ -2149,7 +2155,37 @@ int build_plans(accbpg_dopt* h) {
     const int BN = h->big ? TileBig<false>::BN : TileSmall<false>::BN;
     std::vector<TileRC> tl;
     const int nrb = (int)((m + BM - 1) / BM), ncb = (int)((m + BN - 1) / BN);
-    h->kiters = (h->n + BK - 1) / BK;
+    // Long rows: the Gram matrix is formed column block by column block of V (one launch each, added up in G).  Over a
+    // pass of 16384 k-steps the workgroups of a launch drift apart and stop sharing their panels of V through L2: at
+    // (8192,262144) one launch reached 0.68 of the MFMA peak, the (8192,32768) shape 0.86 -- so rows of 65536 columns or
+    // more are cut into blocks of 32768 (which is also what the eight ranks of BASELINE config 5 hold each).
+    h->gram_chunks = 1;
+    h->gram_nc = h->n;
+    constexpr int64_t GRAM_NC = 32768;
+    if (!(g_plan_flags & 4) && h->big && interior256 && h->use_glds && h->n >= 2 * GRAM_NC && h->n % GRAM_NC == 0) {
+        h->gram_chunks = (int)(h->n / GRAM_NC);
+        h->gram_nc = GRAM_NC;
+        // Rows a megabyte or more apart: a tile of the Gram kernel streams 384 rows of V at once, and with that stride
+        // every one of them sits in a page of its own -- measured on one (8192, 32768) column block: 32.5 ms with rows
+        // 256 or 512 KiB apart, 34.6 ms at 1 MiB, 40.4 ms at 2 MiB (`tools/gram_stride.py`,
+        // profiles/r03_gram_stride.json).  The handle then keeps a copy of V stored block by block ([block][row][32768
+        // columns], made once, here) and the Gram launches read that; everything else keeps reading the caller's V,
+        // which must not change while the handle lives.
+        if (!(g_plan_flags & 8) && h->ldv * (int64_t)sizeof(double) >= (1 << 20)) {
+            const size_t bytes = sizeof(double) * (size_t)m * (size_t)h->n;
+            if (hipMalloc(&h->Vblk, bytes) == hipSuccess) {
+                for (int c = 0; c < h->gram_chunks; ++c)
+                    ACC_HIP(hipMemcpy2DAsync(h->Vblk + (size_t)c * m * GRAM_NC, sizeof(double) * GRAM_NC,
+                                             h->V + (size_t)c * GRAM_NC, sizeof(double) * (size_t)h->ldv,
+                                             sizeof(double) * GRAM_NC, (size_t)m, hipMemcpyDeviceToDevice, h->stream));
+                ACC_HIP(hipStreamSynchronize(h->stream));
+            } else {
+                (void)hipGetLastError();                        // no room for the copy: read V where it lies
+                h->Vblk = nullptr;
+            }
+        }
+    }
+    h->kiters = (h->gram_nc + BK - 1) / BK;
     // 256x128 tiles: the tile (rb, 2rb+1) next to the diagonal holds one useful 128 x 128 block, the odd
     // diagonal block 2rb+1, under 128 rows that lie strictly above the diagonal.  On the direct-to-LDS
     // path those blocks run as dual tiles instead (half of K each at full MFMA work), two per entry.
@@ -2330,7 +2366,7 @@ int build_plans(accbpg_dopt* h) {
                     const int64_t lo = dual ? (hs ? half : 0) : 0, hi = dual ? (hs ? kit : half) : kit;
                     const int64_t ue = std::min(hi, off + (it1 - it));
                     const bool whole = (off == lo && ue == hi);
-                    if (dual || !whole) cl[(size_t)e * 2 + hs].push_back(Contrib{off, w, seg});
+                    if (dual || !whole || h->gram_chunks > 1) cl[(size_t)e * 2 + hs].push_back(Contrib{off, w, seg});
                     it += ue - off;
                     ++seg;
                 }
@@ -2482,32 +2518,44 @@ int build_plans(accbpg_dopt* h) {
 
 template <class T>
 static void gram_launch_t(accbpg_dopt* h, const double* x, double* gram) {
-    prof_begin(h, PROF_GRAM);
     if constexpr (!T::EDGE && T::BM == 256) {
-        // production: the dealt-out schedule, placement B (GRAM_GV); the development switch selects placement A (1) or
-        // the block schedule of round 2 (3) -- all three give bit-identical results
-        if ((h->use_glds || h->has_duals) && h->kern_variant == 1)
-            gram_streamk_glds_kernel<T, 32><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
-                h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m);
-        else if ((h->use_glds || h->has_duals) && h->kern_variant == 3)
-            gram_streamk_glds_kernel<T, 0><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
-                h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m);
-        else if (h->use_glds || h->has_duals)
-            gram_streamk_glds_kernel<T, GRAM_GV><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
-                h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m);
-        else
-            gram_streamk_kernel<T><<<h->gram_grid, NTHREADS, T::LDS_BYTES, h->stream>>>(
-                h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m,
-                h->vec_ok);
-    } else {
-        gram_streamk_kernel<T><<<h->gram_grid, NTHREADS, T::LDS_BYTES, h->stream>>>(
-            h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m,
-            h->vec_ok);
+        if (h->use_glds || h->has_duals) {
+            // production: the dealt-out schedule, placement B (GRAM_GV); the development switch selects placement A (1)
+            // or the block schedule of round 2 (3) -- all three give bit-identical results.
+            // Long rows (gram_chunks > 1): one launch per column block of V, each adding its Gram matrix to G.
+            const int64_t nc = h->gram_chunks > 1 ? h->gram_nc : h->n;
+            for (int c = 0; c < h->gram_chunks; ++c) {
+                const double* Vc = h->Vblk ? h->Vblk + (int64_t)c * h->m * nc : h->V + (int64_t)c * nc;
+                const int64_t ldc = h->Vblk ? nc : h->ldv;
+                const double* xc = x + (int64_t)c * nc;
+                const double beta = c == 0 ? 0.0 : 1.0;
+                const int all_slabs = h->gram_chunks > 1 ? 1 : 0;   // (the plan of a chunked handle lists every segment)
+                prof_begin(h, PROF_GRAM);
+                if (h->kern_variant == 1)
+                    gram_streamk_glds_kernel<T, 32><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
+                        Vc, ldc, h->m, nc, xc, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m, all_slabs);
+                else if (h->kern_variant == 3)
+                    gram_streamk_glds_kernel<T, 0><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
+                        Vc, ldc, h->m, nc, xc, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m, all_slabs);
+                else
+                    gram_streamk_glds_kernel<T, GRAM_GV><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
+                        Vc, ldc, h->m, nc, xc, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m, all_slabs);
+                prof_end(h, PROF_GRAM);
+                prof_begin(h, PROF_GRAMFIX);
+                gram_fixup_kernel<T><<<h->ntiles * 2 * T::MI * FIX_PJ, NTHREADS, 0, h->stream>>>(
+                    h->tiles, h->gram_cstart, h->gram_contrib, h->gram_nslot, h->slabs, gram, h->m, h->m, beta);
+                prof_end(h, PROF_GRAMFIX);
+            }
+            return;
+        }
     }
+    prof_begin(h, PROF_GRAM);
+    gram_streamk_kernel<T><<<h->gram_grid, NTHREADS, T::LDS_BYTES, h->stream>>>(
+        h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m, h->vec_ok);
     prof_end(h, PROF_GRAM);
     prof_begin(h, PROF_GRAMFIX);
     gram_fixup_kernel<T><<<h->ntiles * 2 * T::MI * FIX_PJ, NTHREADS, 0, h->stream>>>(h->tiles, h->gram_cstart, h->gram_contrib, h->gram_nslot,
-                                                                h->slabs, gram, h->m, h->m);
+                                                                h->slabs, gram, h->m, h->m, 0.0);
     prof_end(h, PROF_GRAMFIX);
 }
 
@@ -2525,7 +2573,7 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
         h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, h->Tbuf, h->m, h->vec_ok)
 #define ACC_LAUNCH_G(GG)                                                                                         \
     gram_streamk_glds_kernel<T, GG><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(                      \
-        h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, h->Tbuf, h->m)
+        h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, h->Tbuf, h->m, 0)
         switch (var) {
             case 10: ACC_LAUNCH_G(0); break;
             case 11: ACC_LAUNCH_G(1); break;
@@ -2590,7 +2638,7 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
 
 int launch_gram(accbpg_dopt* h, const double* x, double* gram) {
     bool xal = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    if (!xal && h->has_duals) {
+    if (!xal && (h->has_duals || h->gram_chunks > 1)) {
         // the tile list was built for the direct-to-LDS kernel, which reads x in 16-byte pieces
         if (!h->xbuf) ACC_HIP(hipMalloc(&h->xbuf, sizeof(double) * (size_t)h->n));
         ACC_TRY(device_copy(h->xbuf, x, (size_t)h->n, h->stream));

@@ -133,6 +133,9 @@ struct accbpg_dopt {
     int32_t* gram_contrib = nullptr;  // (workgroup, slab slot) pairs in k order
     int ntiles = 0, gram_grid = 0, gram_per = 0, gram_nslot = 2;
     int64_t kiters = 0;
+    int gram_chunks = 1;        // column blocks of V the Gram matrix is formed over (one launch each; rows >= 65536 long)
+    int64_t gram_nc = 0;        // columns per block
+    double* Vblk = nullptr;     // owned copy of V stored block by block (rows >= 1 MiB apart only), read by the Gram launches
     double* dscal = nullptr;    // device scalars
     int* dflag = nullptr;       // device status flags
     double* hpin = nullptr;     // pinned host mirror (scalars then flags)

@@ -583,7 +583,14 @@ def main():
             if lockstep is not None:
                 per_launch = ipg / float(-(-ipg // max(1, lockstep.chunk)))
             flops = float(m) * m * n_local * per_launch
-            achieved = flops / (gram_ms / gram_cnt * 1e-3) * 1e-12 if gram_cnt else None
+            # rows of 65536 columns or more: the Gram matrix is formed by one launch per column block of 32768 (the
+            # library's choice); the algorithmic flops of ONE launch are those of its block
+            evals = (calls["value"] + calls["grad"]) * args.steps * (1 if lockstep is not None else ninst_local)
+            gram_blocks = 1
+            if lockstep is None and gram_cnt and evals:
+                gram_blocks = max(1, int(round(gram_cnt / float(evals))))
+            gram_flops = flops / gram_blocks
+            achieved = gram_flops / (gram_ms / gram_cnt * 1e-3) * 1e-12 if gram_cnt else None
             traffic = None
             try:        # HBM bytes per launch from this round's PMC passes (same workload only)
                 tj = json.load(open(TRAFFIC_FILE))
@@ -599,7 +606,7 @@ def main():
                                                   "process), not in this run" % os.path.relpath(TRAFFIC_FILE, ROOT))
                                                  if traffic else None,
                                "avg_launch_ms": gram_ms / gram_cnt if gram_cnt else None, "launches": gram_cnt,
-                               "instances_per_launch": per_launch,
+                               "instances_per_launch": per_launch, "column_blocks_per_evaluation": gram_blocks,
                                "timing": ("HIP events around every launch on the launching stream, "
                                           + ("over %d further steps of the same run right behind the timed region"
                                              % args.steps if lockstep is not None else "inside the timed region"))

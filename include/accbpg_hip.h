@@ -42,7 +42,8 @@ const char* accbpg_last_error(void);
 /* ---- D-optimal objective: replaces DOptimalObj (accbpg/functions.py:27-59) ------------ */
 
 /* Borrow V (m x n, row-major, leading dimension ldv >= n; the reference's `self.H`,
- * functions.py:32).  V must outlive the handle.  The handle owns all workspace
+ * functions.py:32).  V must outlive the handle and must not change while it lives (for rows a megabyte or more
+ * apart the handle keeps a copy of V stored in column blocks, which its Gram launches read).  The handle owns all workspace
  * (Gram matrix, Cholesky factor, inverse factor, stream-K slabs, pinned scalars).
  * is_shard != 0: V is a column block of a larger instance (design-point sharding), so the
  * reference's m < n precondition (functions.py:35) applies to the whole instance, not to it. */

@@ -149,6 +149,41 @@ def test_gram_unaligned_x_through_c_abi(acc, O):
     np.testing.assert_allclose(g.cpu().numpy(), gr, rtol=1e-11)
 
 
+@pytest.mark.parametrize("n,ld", [(65536, 65536), (131072, 131072), (65536, 196608)])
+def test_long_rows_column_blocks_against_oracle(acc, O, n, ld):
+    """Rows of 65536 columns or more: the Gram matrix is formed column block by column block of V (one launch per block of
+    32768, every segment through a slab, the fix-up launches add the blocks up), and where consecutive rows lie a
+    megabyte or more apart (leading dimension >= 131072) the launches read a copy of V stored block by block that the
+    handle makes once.  All three cases against the oracle through the C-ABI: blocks only; blocks + copy; blocks + copy of
+    a matrix that is a column range of a wider one (ldv > n).  The x handed in is only 8-byte aligned."""
+    from accbpg_and_fw_amd import _lib
+    lib = _lib.load()
+    m = 768
+    gen = torch.Generator(device="cuda").manual_seed(n + ld)
+    wide = torch.randn(m, ld, dtype=torch.float64, device="cuda", generator=gen)
+    V = wide[:, :n]
+    x = torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) + 0.05
+    x /= x.sum()
+    buf = torch.zeros(n + 1, dtype=torch.float64, device="cuda")
+    buf[1:] = x
+    h = C.c_void_p()
+    _lib.check(lib.accbpg_dopt_create(C.c_void_p(wide.data_ptr()), m, n, ld, None, C.byref(h), 0), "accbpg_dopt_create")
+    try:
+        g = torch.empty(n, dtype=torch.float64, device="cuda")
+        fv = C.c_double()
+        fr, gr = O.DOptOracle(V.cpu().numpy()).func_grad(x.cpu().numpy(), 2)
+        for xp in (x.data_ptr(), buf.data_ptr() + 8):
+            assert lib.accbpg_dopt_func_grad(h, C.c_void_p(xp), 2, C.byref(fv), C.c_void_p(g.data_ptr())) == 0
+            torch.cuda.synchronize()
+            assert abs(fv.value - fr) < 1e-11 * abs(fr)
+            np.testing.assert_allclose(g.cpu().numpy(), gr, rtol=1e-10)
+        f0 = C.c_double()
+        assert lib.accbpg_dopt_func_grad(h, C.c_void_p(x.data_ptr()), 0, C.byref(f0), None) == 0
+        assert f0.value == fv.value                             # the value-only evaluation: the same Gram matrix
+    finally:
+        lib.accbpg_dopt_destroy(h)
+
+
 def test_func_grad_errors(acc):
     """AssertionError / ValueError behaviour of accbpg/functions.py:44-50."""
     f, h, L, x0 = acc.D_opt_design(8, 20, randseed=3)
