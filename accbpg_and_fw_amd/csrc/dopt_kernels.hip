@@ -2745,8 +2745,12 @@ int launch_cholesky(accbpg_dopt* h, double* A, double* Winv, const double* xchec
     if (src == nullptr) src = A;
     const bool tiles = chol_tiles_usable(h);
     prof_begin(h, PROF_CHOL);
-    zero_scalars_kernel<<<1, (xcheck || tiles) ? 1024 : 64, 0, h->stream>>>(h->dscal, h->dflag, xcheck, h->n,
-                                                                          tiles ? h->chol_ready : nullptr, tiles ? T * T + 5 * T : 0);
+    // 512 threads, not 1024: two waves of 32 registers per SIMD fit beside a wave of the Gram kernel (392 of the 512
+    // registers of a SIMD lane), four do not -- and this launch often meets the OTHER stream's Gram launch, which holds
+    // every compute unit for 2 ms (its rocprofv3 average with 1024 threads in the steady state of ABPG_gain: 328 us,
+    // nearly all of it waiting for a compute unit)
+    zero_scalars_kernel<<<1, (xcheck || tiles) ? 512 : 64, 0, h->stream>>>(h->dscal, h->dflag, xcheck, h->n,
+                                                                         tiles ? h->chol_ready : nullptr, tiles ? T * T + 5 * T : 0);
     if (tiles) {
         ACC_TRY(launch_chol_tiles(h, src, A, Winv));
         h->diag_inv_ready = (Winv != nullptr);
@@ -2867,7 +2871,7 @@ int launch_cholesky_batch(accbpg_dopt_batch* b, const BatchAct& act, bool with_i
     const int64_t m = h0->m;
     const int T = (int)((m + NB - 1) / NB);
     prof_begin(h0, PROF_CHOL);
-    zero_scalars_batch_kernel<<<act.n, 1024, 0, b->stream>>>(b->table, act, xbase, ldx, h0->n, T * T + 5 * T);
+    zero_scalars_batch_kernel<<<act.n, 512, 0, b->stream>>>(b->table, act, xbase, ldx, h0->n, T * T + 5 * T);
     const int dev = (b->device >= 0 && b->device < 64) ? b->device : 0;
     const int grid_all = h0->chol_tiles_grid * act.n;
     std::lock_guard<std::mutex> lk(g_tiles_mu);

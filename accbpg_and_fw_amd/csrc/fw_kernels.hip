@@ -116,6 +116,56 @@ __global__ __launch_bounds__(FB) void fw_probe_final_kernel(const ValIdx* __rest
     }
 }
 
+// Away variant, stage 2 on many workgroups (one workgroup scanning 2n doubles took 40 us of a 170 us step at n = 32768):
+// every workgroup combines the stage-1 maxima itself (at most 512 records: the same w_i everywhere), then takes the
+// first-index minimum of d_k = (w_k - w_i) * [x_k > 1e-8] -- formed exactly as the reference forms it, D_opt_alg.py:146-147
+// -- over its slice; workgroup 0 leaves (w_i, i) for the final stage.
+constexpr int AWAY_NB = 128;        // at most this many slices
+__global__ __launch_bounds__(FB) void fw_probe_away_partial_kernel(const ValIdx* __restrict__ part, int nblk,
+                                                                  const double* __restrict__ w,
+                                                                  const double* __restrict__ x, int64_t n,
+                                                                  ValIdx* __restrict__ part2, ValIdx* __restrict__ mxslot) {
+    __shared__ ValIdx sh[FB / 64];
+    const double inf = __builtin_inf();
+    ValIdx best{-inf, INT64_MAX};
+    for (int b = threadIdx.x; b < nblk; b += FB) best = better_max(best, part[2 * b]);
+    const ValIdx mx = block_reduce_vi_n<true, FB>(best, sh);
+    ValIdx dm{inf, INT64_MAX};
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t k0 = (int64_t)blockIdx.x * per, k1 = min(n, k0 + per);
+    for (int64_t k = k0 + threadIdx.x; k < k1; k += FB) {
+        const double diff = w[k] - mx.v;
+        const double dk = diff * ((x[k] > 1.0e-8) ? 1.0 : 0.0);
+        dm = better_min(dm, ValIdx{dk, k});
+    }
+    const ValIdx mn = block_reduce_vi_n<false, FB>(dm, sh);
+    if (threadIdx.x == 0) {
+        part2[blockIdx.x] = mn;
+        if (blockIdx.x == 0) *mxslot = mx;
+    }
+}
+__global__ __launch_bounds__(FB) void fw_probe_away_final_kernel(const ValIdx* __restrict__ part2, int nb2,
+                                                                const ValIdx* __restrict__ mxslot,
+                                                                const double* __restrict__ w,
+                                                                const double* __restrict__ x, int64_t n,
+                                                                double* __restrict__ dout, int64_t* __restrict__ iout) {
+    __shared__ ValIdx sh[FB / 64];
+    const double inf = __builtin_inf();
+    ValIdx dm{inf, INT64_MAX};
+    for (int b = threadIdx.x; b < nb2; b += FB) dm = better_min(dm, part2[b]);
+    const ValIdx mn = block_reduce_vi_n<false, FB>(dm, sh);
+    if (threadIdx.x == 0) {
+        const ValIdx mx = *mxslot;
+        const int64_t j = mn.i;
+        iout[0] = mx.i;
+        iout[1] = j;
+        dout[0] = mx.v;
+        const bool ok = j >= 0 && j < n;
+        dout[1] = ok ? w[j] : inf;
+        dout[2] = ok ? x[j] : 0.0;
+    }
+}
+
 // x <- x*xscale; x[p] += xadd   (D_opt_alg.py:76-77,164-165,173-174); vp <- V[:,p]
 __global__ __launch_bounds__(FB) void fw_xupdate_gather_kernel(double* __restrict__ x, int64_t n, int64_t p,
                                                               double xscale, double xadd,
@@ -353,7 +403,8 @@ static int fw_alloc(accbpg_dopt* h) {
     ACC_HIP(hipMalloc(&h->fw_x, sizeof(double) * h->n));
     ACC_HIP(hipMalloc(&h->fw_w, sizeof(double) * h->n));
     ACC_HIP(hipMalloc(&h->fw_H, sizeof(double) * h->m * h->m));
-    ACC_HIP(hipMalloc(&h->fw_hv, sizeof(double) * (2 * h->m + 2 * 1024 + 16)));   // Hv, vp, probe partials
+    // Hv, vp, 2 * 512 stage-1 probe records, AWAY_NB stage-2 records + (w_i, i) of the away variant
+    ACC_HIP(hipMalloc(&h->fw_hv, sizeof(double) * (2 * h->m + 2 * 1024 + 16 + 2 * AWAY_NB + 4)));
     return ACCBPG_OK;
 }
 
@@ -540,7 +591,16 @@ extern "C" int accbpg_fw_probe_step(accbpg_dopt* h, int away, int refresh_logdet
     }
     h->fw_part_nblk = 0;
     h->fw_part_away = (away != 0);
-    fw_probe_final_kernel<<<1, FB, 0, h->stream>>>(part, nblk, h->fw_w, h->fw_x, h->n, away, h->dscal + 4, iout);
+    if (away && h->n >= 4096) {
+        ValIdx* part2 = part + 2 * 512;
+        ValIdx* mxslot = part2 + AWAY_NB;
+        int nb2 = (int)((h->n + (int64_t)FB * 8 - 1) / ((int64_t)FB * 8));
+        if (nb2 > AWAY_NB) nb2 = AWAY_NB;
+        fw_probe_away_partial_kernel<<<nb2, FB, 0, h->stream>>>(part, nblk, h->fw_w, h->fw_x, h->n, part2, mxslot);
+        fw_probe_away_final_kernel<<<1, FB, 0, h->stream>>>(part2, nb2, mxslot, h->fw_w, h->fw_x, h->n, h->dscal + 4, iout);
+    } else {
+        fw_probe_final_kernel<<<1, FB, 0, h->stream>>>(part, nblk, h->fw_w, h->fw_x, h->n, away, h->dscal + 4, iout);
+    }
     ACC_HIP(hipGetLastError());
     ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * 12, hipMemcpyDeviceToHost, h->stream));
     ACC_HIP(hipStreamSynchronize(h->stream));
