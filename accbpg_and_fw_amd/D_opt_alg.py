@@ -9,6 +9,7 @@ reference writes them, and issues one rank-one update.
 from __future__ import annotations
 
 import ctypes as C
+import math
 import time
 
 import numpy as np
@@ -34,11 +35,20 @@ class _FWState:
         _lib.check(rc, "accbpg_fw_init")
         self.logdet_gram = logdet.value
 
+    def _on_device(self):
+        """True when the objective's device is already the current one (then the two calls per iteration skip the
+        device context manager: a few microseconds each, against a step of 0.12-0.15 ms)."""
+        return torch.cuda.current_device() == self.obj.device.index
+
     def probe(self, away, refresh_logdet):
         pr = _lib.FwProbe()
-        with torch.cuda.device(self.obj.device):
+        if self._on_device():
             rc = self.lib.accbpg_fw_probe_step(self.h, int(away), int(refresh_logdet), C.byref(pr))
-        _lib.check(rc, "accbpg_fw_probe_step")
+        else:
+            with torch.cuda.device(self.obj.device):
+                rc = self.lib.accbpg_fw_probe_step(self.h, int(away), int(refresh_logdet), C.byref(pr))
+        if rc:
+            _lib.check(rc, "accbpg_fw_probe_step")
         return pr
 
     def logdet_ring(self, depth, small_launches=2):
@@ -56,9 +66,13 @@ class _FWState:
         return out.value
 
     def update(self, p, xscale, xadd, hcoef, hdiv):
-        with torch.cuda.device(self.obj.device):
+        if self._on_device():
             rc = self.lib.accbpg_fw_update(self.h, int(p), float(xscale), float(xadd), float(hcoef), float(hdiv))
-        _lib.check(rc, "accbpg_fw_update")
+        else:
+            with torch.cuda.device(self.obj.device):
+                rc = self.lib.accbpg_fw_update(self.h, int(p), float(xscale), float(xadd), float(hcoef), float(hdiv))
+        if rc:
+            _lib.check(rc, "accbpg_fw_update")
 
     def x(self):
         out = torch.empty(self.n, dtype=torch.float64, device=self.obj.device)
@@ -216,7 +230,8 @@ def D_opt_FW_away_steps(V, x0, eps, maxitrs, verbose=True, verbskip=1, logdet_re
         T[k] = time.time() - start_time
         if step is not None:
             hcoef, hdiv = step
-            delta[k - 1] = np.log1p(hcoef * pr.q_prev) - m * np.log(hdiv)
+            arg = hcoef * pr.q_prev
+            delta[k - 1] = (math.log1p(arg) - m * math.log(hdiv)) if (arg > -1.0 and hdiv > 0.0) else float("nan")
         if refresh:
             if len(anchors) >= depth:
                 settle(anchors.pop(0), pr.logdet_H)

@@ -481,6 +481,10 @@ static int fw_ring_setup(accbpg_dopt* h) {
         }
         h->fw_ring.push_back(sl);
     }
+    for (auto& sl : h->fw_ring) {                              // (development switches of the main handle apply to its slots)
+        sl.aux->chol_stall_test = h->chol_stall_test;
+        sl.aux->chol_spin_limit = h->chol_spin_limit;
+    }
     return ACCBPG_OK;
 }
 

@@ -916,6 +916,13 @@ def test_tile_cholesky_gives_up_and_redoes(acc):
     xb, Fb, SPb, SNb, Tb = acc.D_opt_FW_away(f, x0, 1e-8, 5, verbose=False)
     np.testing.assert_array_equal(xa, xb)
     np.testing.assert_array_equal(Fa, Fb)
+    # ... and so do the side factorisations of F[k] = log det(H_k) (a ring of auxiliary handles, here one per iteration)
+    g3 = acc.DOptimalObj(f.H)
+    _lib.load().accbpg_debug_chol_variant(g3._h, 128)
+    xc, Fc, SPc, SNc, Tc = acc.D_opt_FW_away(g3, x0, 1e-8, 7, verbose=False, logdet_refresh=1, logdet_ring=3)
+    xd, Fd, SPd, SNd, Td = acc.D_opt_FW_away(f, x0, 1e-8, 7, verbose=False, logdet_refresh=1, logdet_ring=1)
+    np.testing.assert_array_equal(xc, xd)
+    np.testing.assert_array_equal(Fc, Fd)
 
 
 # ------------------------------------------------------------------ sharding (one device, logical shards)
