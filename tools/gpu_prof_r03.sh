@@ -49,6 +49,7 @@ run_bench bench_cfg5_full --config 5 --gpus 1 --steps 5 --warmup 2 --no-cpu-base
 run_bench bench_cfg4_64 --config 4 --instances-per-gpu 64 --steps 50 --warmup 10 --no-steady --no-cpu-baseline
 run_bench bench_fw_away_exact --config 3 --steps 300 --warmup 20 --logdet-refresh 1 --no-cpu-baseline
 run_bench bench_lingram_steady --linear-gram --steps 20 --warmup 5 --no-cpu-baseline
+run_bench bench_memo_steady --memo-values --steps 20 --warmup 5 --no-cpu-baseline
 run_bench bench_poisson --workload poisson_abpg --steps 50 --warmup 5
 fi
 if [ "${STAGE:-all}" = "all" ] || [ "$STAGE" = "prof" ] || [ "$STAGE" = "pmc" ]; then
