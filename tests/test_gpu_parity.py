@@ -893,6 +893,31 @@ def test_tile_cholesky_matches_step_kernels(acc, O, m):
     assert f_tiles(x) == a                                       # and the handle is fine afterwards
 
 
+@pytest.mark.parametrize("shape", [(768, 2048), (1024, 4096), (2048, 8192), (4096, 8192)])
+def test_gram_schedules_are_bit_identical(acc, shape):
+    """The production Gram kernel deals its staging instructions out between MFMA pairs (placement B); the development
+    switch still selects placement A and round 2's block schedule.  Same MFMAs in the same order: value and gradient are
+    the same to the bit under all three (aligned stream-K ranges with dual tiles; whole tiles per workgroup at m = 4096)."""
+    from accbpg_and_fw_amd import _lib
+    lib = _lib.load()
+    m, n = shape
+    gen = torch.Generator(device="cuda").manual_seed(m + n)
+    V = torch.randn(m, n, dtype=torch.float64, device="cuda", generator=gen)
+    x = torch.rand(n, dtype=torch.float64, device="cuda", generator=gen) + 0.05
+    x /= x.sum()
+    f = acc.DOptimalObj(V)
+    base = f.func_grad(x, 2)
+    try:
+        for variant in (1, 3, 2):
+            lib.accbpg_debug_chol_variant(f._h, variant << 30)
+            fv, g = f.func_grad(x, 2)
+            assert fv == base[0], variant
+            assert torch.equal(g, base[1]), variant
+    finally:
+        lib.accbpg_debug_chol_variant(f._h, 0)
+    assert f.func_grad(x, 2)[0] == base[0]
+
+
 def test_tile_cholesky_gives_up_and_redoes(acc):
     """A wait inside the one-launch Cholesky that is never satisfied (here: a test hook keeps block column 0
     unpublished) ends the launch by its bounded spin instead of hanging it; the evaluation is redone with the
