@@ -284,7 +284,7 @@ def large_abpg_1000(accbpg, m=2048, n=32768, seed=10, iters=1000, keep=(250, 500
     save("large_abpg_1000", **out)
 
 
-def large_fw_long(accbpg, m=2048, n=32768, seed=10, iters=1000):
+def large_fw_long(accbpg, m=2048, n=32768, seed=10, iters=1000, name="large_fw_long"):
     """Config 3 (BASELINE.json): D_opt_FW and D_opt_FW_away at (2048, 32768) for 1000 iterations from x0 = 1/n
     (accbpg/D_opt_alg.py:9-88, 91-187): final iterates and the per-iteration traces (objective, dual gap /
     positive and negative gaps), which pin every step choice along the way."""
@@ -297,18 +297,18 @@ def large_fw_long(accbpg, m=2048, n=32768, seed=10, iters=1000):
     t = time.time()
     xa, Fa, SPa, SNa, Ta = accbpg.D_opt_FW_away(V, x0, 1e-8, iters, verbose=True, verbskip=100)
     print("FW away %d its: %.1f s" % (iters, time.time() - t), flush=True)
-    save("large_fw_long", m=m, n=n, seed=seed, iters=iters, fw_x=xf, fw_F=F, fw_SP=SP, fw_SN=SN,
+    save(name, m=m, n=n, seed=seed, iters=iters, fw_x=xf, fw_F=F, fw_SP=SP, fw_SN=SN,
          away_x=xa, away_F=Fa, away_SP=SPa, away_SN=SNa)
 
 
-def large_bpg_long(accbpg, m=2048, n=32768, seed=10, iters=300):
+def large_bpg_long(accbpg, m=2048, n=32768, seed=10, iters=300, name="large_bpg_long"):
     """Config-2 size: BPG with line search for 300 iterations (accbpg/algorithms.py:11-72)."""
     import time
     f, h, L, x0 = accbpg.D_opt_design(m, n, randseed=seed)
     t = time.time()
     x, F, Ls, T = accbpg.BPG(f, h, L, x0, maxitrs=iters, linesearch=True, verbose=True, verbskip=25)
     print("BPG-LS %d its: %.1f s" % (iters, time.time() - t), flush=True)
-    save("large_bpg_long", m=m, n=n, seed=seed, iters=iters, x=x, F=F, Ls=Ls, ref_seconds=T[-1])
+    save(name, m=m, n=n, seed=seed, iters=iters, x=x, F=F, Ls=Ls, ref_seconds=T[-1])
 
 
 def m8192(accbpg, m=8192, n=16400, seed=10, iters=3):
@@ -487,10 +487,16 @@ def main():
         large_abpg_1000(accbpg)
         return
     if args.only_large_fw_long:
-        large_fw_long(accbpg)
+        if args.name != "large_gain_long":                     # (--iters / --name: a longer fixture beside the 1000-iteration one)
+            large_fw_long(accbpg, iters=args.iters, name=args.name)
+        else:
+            large_fw_long(accbpg)
         return
     if args.only_large_bpg_long:
-        large_bpg_long(accbpg)
+        if args.name != "large_gain_long":
+            large_bpg_long(accbpg, iters=args.iters, name=args.name)
+        else:
+            large_bpg_long(accbpg)
         return
     if args.only_next:
         next_rows(accbpg)

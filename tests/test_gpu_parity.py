@@ -814,16 +814,19 @@ def test_factor_in_small_launches_is_the_same_arithmetic(acc):
         assert L.accbpg_dopt_factor_in_small_launches(None, 1) == 4
 
 
-def test_large_fw_1000_iterations_2048x32768(large, acc):
-    """BASELINE config 3 at full length: D_opt_FW and D_opt_FW_away at (2048,32768) for 1000 iterations against the
-    real reference (oracle/gen_golden.py --only-large-fw-long; accbpg/D_opt_alg.py:9-88, 91-187).  The traces hold
-    the objective and the gaps of every iteration, so every vertex choice and step length along the way is pinned.
-    Measured: l_inf(x) 1.7e-18 / 1.8e-18, objective traces to 3e-15 / 1e-14, gap traces to 6e-14 / 5e-14."""
+@pytest.mark.parametrize("fixture", ["large_fw_long", "large_fw_5000"])
+def test_large_fw_1000_iterations_2048x32768(large, acc, fixture):
+    """BASELINE config 3 at full length: D_opt_FW and D_opt_FW_away at (2048,32768) for 1000 iterations -- and, second
+    fixture, for 5000 -- against the real reference (oracle/gen_golden.py --only-large-fw-long [--iters 5000 --name
+    large_fw_5000]; accbpg/D_opt_alg.py:9-88, 91-187).  The traces hold the objective and the gaps of every iteration,
+    so every vertex choice and step length along the way is pinned; D_opt_FW_away runs in its default form (F[k] anchored
+    every 16th iteration, section 3.6 of DESIGN.md).
+    Measured over 1000 iterations: l_inf(x) 1.7e-18 / 1.8e-18, objective traces to 3e-15 / 1e-14, gap traces to 6e-14 / 5e-14."""
     import os
-    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "large_fw_long.npz")):
-        pytest.skip("tests/golden/large_fw_long.npz not generated")
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", fixture + ".npz")):
+        pytest.skip("tests/golden/%s.npz not generated" % fixture)
     f, h, L, x0, _ = large
-    gd = golden("large_fw_long")
+    gd = golden(fixture)
     iters = int(gd["iters"])
     x, F, SP, SN, T = acc.D_opt_FW(f, x0, 1e-8, iters, verbose=False)
     print("FW: l_inf %.2e, F %.2e, SP %.2e" % (np.max(np.abs(x - gd["fw_x"])), np.max(np.abs(F - gd["fw_F"]) / (1 + np.abs(gd["fw_F"]))),
@@ -839,15 +842,17 @@ def test_large_fw_1000_iterations_2048x32768(large, acc):
     _close(F, gd["away_F"], 1e-8); _close(SP, gd["away_SP"], 1e-7); _close(SN, gd["away_SN"], 1e-7)
 
 
-def test_large_bpg_ls_300_iterations_2048x32768(large, acc):
-    """BPG with line search at (2048,32768) for 300 iterations against the real reference (oracle/gen_golden.py
-    --only-large-bpg-long; accbpg/algorithms.py:11-72): the same L_k sequence (every accept/reject decision of the
-    backtracking search), F[k] to 1e-9, the final iterate to l_inf < 1e-9.  Measured: l_inf 2.1e-16, F to 4.5e-13."""
+@pytest.mark.parametrize("fixture", ["large_bpg_long", "large_bpg_1000"])
+def test_large_bpg_ls_300_iterations_2048x32768(large, acc, fixture):
+    """BPG with line search at (2048,32768) for 300 iterations -- and, second fixture, for the north star's 1000 -- against
+    the real reference (oracle/gen_golden.py --only-large-bpg-long [--iters 1000 --name large_bpg_1000];
+    accbpg/algorithms.py:11-72): the same L_k sequence (every accept/reject decision of the backtracking search), F[k] to
+    1e-9, the final iterate to l_inf < 1e-9.  Measured over 300 iterations: l_inf 2.1e-16, F to 4.5e-13."""
     import os
-    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "large_bpg_long.npz")):
-        pytest.skip("tests/golden/large_bpg_long.npz not generated")
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", fixture + ".npz")):
+        pytest.skip("tests/golden/%s.npz not generated" % fixture)
     f, h, L, x0, _ = large
-    gd = golden("large_bpg_long")
+    gd = golden(fixture)
     iters = int(gd["iters"])
     x, F, Ls, T = acc.BPG(f, h, L, x0, maxitrs=iters, linesearch=True, verbose=False)
     print("BPG-LS: l_inf %.2e, F %.2e" % (np.max(np.abs(x - gd["x"])), np.max(np.abs(F - gd["F"]) / (1 + np.abs(gd["F"])))))
