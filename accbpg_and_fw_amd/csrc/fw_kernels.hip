@@ -83,7 +83,10 @@ __global__ __launch_bounds__(FB) void fw_probe_partial_kernel(const double* __re
 __global__ __launch_bounds__(FB) void fw_probe_final_kernel(const ValIdx* __restrict__ part, int nblk,
                                                            const double* __restrict__ w,
                                                            const double* __restrict__ x, int64_t n, int away,
-                                                           double* __restrict__ dout, int64_t* __restrict__ iout) {
+                                                           double* __restrict__ dout, int64_t* __restrict__ iout,
+                                                           const double* __restrict__ qsrc) {
+    // (dout / iout point into the handle's PINNED HOST record: the results -- and q of the last update, qsrc -- are
+    //  written where the host reads them, no copy operation behind the kernel)
     __shared__ ValIdx sh[FB / 64];
     const double inf = __builtin_inf();
     ValIdx best{-inf, INT64_MAX}, lo{inf, INT64_MAX};
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(FB) void fw_probe_final_kernel(const ValIdx* __rest
         const bool ok = j >= 0 && j < n;
         dout[1] = ok ? w[j] : inf;
         dout[2] = ok ? x[j] : 0.0;
+        dout[6] = *qsrc;
     }
 }
 
@@ -148,7 +152,8 @@ __global__ __launch_bounds__(FB) void fw_probe_away_final_kernel(const ValIdx* _
                                                                 const ValIdx* __restrict__ mxslot,
                                                                 const double* __restrict__ w,
                                                                 const double* __restrict__ x, int64_t n,
-                                                                double* __restrict__ dout, int64_t* __restrict__ iout) {
+                                                                double* __restrict__ dout, int64_t* __restrict__ iout,
+                                                                const double* __restrict__ qsrc) {
     __shared__ ValIdx sh[FB / 64];
     const double inf = __builtin_inf();
     ValIdx dm{inf, INT64_MAX};
@@ -163,6 +168,7 @@ __global__ __launch_bounds__(FB) void fw_probe_away_final_kernel(const ValIdx* _
         const bool ok = j >= 0 && j < n;
         dout[1] = ok ? w[j] : inf;
         dout[2] = ok ? x[j] : 0.0;
+        dout[6] = *qsrc;
     }
 }
 
@@ -400,6 +406,7 @@ using namespace accbpg;
 
 static int fw_alloc(accbpg_dopt* h) {
     if (h->fw_x) return ACCBPG_OK;
+    ACC_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->fw_hpin_dev), h->hpin, 0));   // the pinned record, as the device addresses it
     ACC_HIP(hipMalloc(&h->fw_x, sizeof(double) * h->n));
     ACC_HIP(hipMalloc(&h->fw_w, sizeof(double) * h->n));
     ACC_HIP(hipMalloc(&h->fw_H, sizeof(double) * h->m * h->m));
@@ -583,7 +590,8 @@ extern "C" int accbpg_fw_probe_step(accbpg_dopt* h, int away, int refresh_logdet
         logdet = h->hpin[0];
         if (fl[FLAG_NOT_PD]) logdet = __builtin_nan("");
     }
-    int64_t* iout = reinterpret_cast<int64_t*>(h->dscal + 8);
+    double* dout = h->fw_hpin_dev + 4;
+    int64_t* iout = reinterpret_cast<int64_t*>(h->fw_hpin_dev + 8);
     int nblk = (int)((h->n + (int64_t)FB * 8 - 1) / ((int64_t)FB * 8));
     if (nblk < 1) nblk = 1;
     if (nblk > 512) nblk = 512;
@@ -601,12 +609,13 @@ extern "C" int accbpg_fw_probe_step(accbpg_dopt* h, int away, int refresh_logdet
         int nb2 = (int)((h->n + (int64_t)FB * 8 - 1) / ((int64_t)FB * 8));
         if (nb2 > AWAY_NB) nb2 = AWAY_NB;
         fw_probe_away_partial_kernel<<<nb2, FB, 0, h->stream>>>(part, nblk, h->fw_w, h->fw_x, h->n, part2, mxslot);
-        fw_probe_away_final_kernel<<<1, FB, 0, h->stream>>>(part2, nb2, mxslot, h->fw_w, h->fw_x, h->n, h->dscal + 4, iout);
+        fw_probe_away_final_kernel<<<1, FB, 0, h->stream>>>(part2, nb2, mxslot, h->fw_w, h->fw_x, h->n, dout, iout, h->dscal + 10);
     } else {
-        fw_probe_final_kernel<<<1, FB, 0, h->stream>>>(part, nblk, h->fw_w, h->fw_x, h->n, away, h->dscal + 4, iout);
+        fw_probe_final_kernel<<<1, FB, 0, h->stream>>>(part, nblk, h->fw_w, h->fw_x, h->n, away, dout, iout, h->dscal + 10);
     }
     ACC_HIP(hipGetLastError());
-    ACC_HIP(hipMemcpyAsync(h->hpin, h->dscal, sizeof(double) * 12, hipMemcpyDeviceToHost, h->stream));
+    // (the final stage wrote its record straight into the pinned host buffer: the copy operation that used to follow it
+    //  was 4 us of every 0.12 ms step)
     ACC_HIP(hipStreamSynchronize(h->stream));
     const int64_t* ih = reinterpret_cast<const int64_t*>(h->hpin + 8);
     out->i = ih[0];

@@ -154,6 +154,7 @@ struct accbpg_dopt {
 
     // Frank-Wolfe state
     double *fw_x = nullptr, *fw_w = nullptr, *fw_H = nullptr, *fw_hv = nullptr;
+    double* fw_hpin_dev = nullptr;  // device address of the pinned host record hpin (the probe's final stage writes there)
     bool fw_ready = false;
     // log det(H) of the away-step variant (D_opt_alg.py:136) factored beside the steps: a ring of snapshot slots, each an
     // auxiliary handle (own buffers, own stream) that factors a copy of H_k while the main stream goes on
