@@ -450,7 +450,10 @@ __device__ __forceinline__ void gram_fixup_body(
         if (j < j1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t row = row0 + 16 * (part * T::WAVES_M + wm) + lq + 4 * r;
+                // (a dual tile's fragment row `part` of wave wm covers row block dual_row_block(part, wm): the same set
+                //  of four blocks as part * WAVES_M + wm, dealt to the waves so that each carries 9 fragments)
+                const int rblk = dual ? T::dual_row_block(part, wm) : part * T::WAVES_M + wm;
+                const int64_t row = row0 + 16 * rblk + lq + 4 * r;
                 const int64_t col = col0 + wn * T::WN + 16 * j + lr;
                 if (row < m && col < m && col <= row) {
                     double* gp = G + row * ldg + col;

@@ -452,15 +452,22 @@ struct Tile {
                                          (__attribute__((address_space(3))) void*)(stage + G_A + G_B), 4, 0, 0);
     }
     static constexpr int G_NLD_DUAL = G_NA + 1;
+    // Which 16-row block of the 128-row band fragment row i2 (= i mod MI/2) of wave `w` covers in a dual tile.  Row
+    // block b of the lower triangle holds b + 1 fragments, so a wave takes the blocks w and 7 - w: 9 fragments for
+    // every wave (with the blocks w and 4 + w of the ordinary layout wave 3 would carry 12 and wave 0 only 6, and the
+    // slowest wave sets the time of the step).  Which wave forms a fragment does not enter its arithmetic.
+    static __device__ __forceinline__ int dual_row_block(int i2, int w) {
+        return i2 ? (2 * WAVES_M - 1 - w) : w;                  // (dual tiles exist for the 256 x 128 tile only: MI / 2 = 2, WAVES_M = 4)
+    }
     template <int SET>
     __device__ __forceinline__ void read_frag_dual(const double* __restrict__ stage, int kk) {
         const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const int lr = lane & 15, lq = lane >> 4;
         const int sw = (lr >> 1) & 7;
         const int koff = 2 * ((2 * kk + (lq >> 1)) ^ sw) + (lq & 1);
-        const double* as = stage + (16 * wave + lr) * BK + koff;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) fa[SET][i] = as[i * 16 * WAVES_M * BK];
+        for (int i = 0; i < MI; ++i)
+            fa[SET][i] = stage[((i / (MI / 2)) * (BM / 2) + 16 * dual_row_block(i % (MI / 2), wave) + lr) * BK + koff];
         const double* bs = stage + lr * BK + koff;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -476,14 +483,14 @@ struct Tile {
 #pragma unroll
         for (int i = 0; i < MI; ++i) fa[SET][i] *= (i < MI / 2) ? fx[SET] : fx2[SET];
     }
-    // Fragment (i, j) of the diagonal block covers rows 64*(i mod MI/2) + 16*wave .. +15 and columns
-    // 16j .. 16j+15: it lies strictly above the diagonal, and is skipped, when j > 4*(i mod MI/2) + wave.
+    // Fragment (i, j) of the diagonal block covers the 16-row block dual_row_block(i mod MI/2, wave) and columns
+    // 16j .. 16j+15: it lies strictly above the diagonal, and is skipped, when j > that row block.
     template <int SET>
     __device__ __forceinline__ void mma_dual() {
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int lim = (16 * WAVES_M / 16) * (i % (MI / 2)) + wave;
+            const int lim = dual_row_block(i % (MI / 2), wave);
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 if (j > lim) break;
