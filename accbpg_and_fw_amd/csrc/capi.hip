@@ -37,7 +37,9 @@ static int read_status(accbpg_dopt* h) {
 
 using namespace accbpg;
 
-extern "C" int accbpg_abi_version(void) { return 2; }   // 2: batches, one-launch Cholesky, pipelined FW log det
+// 2: batches, one-launch Cholesky, pipelined FW log det
+// 3: accbpg_fw_probe grew q_prev; ring of side factorisations (accbpg_fw_logdet_ring / _pending); accbpg_dopt_batch_chunk
+extern "C" int accbpg_abi_version(void) { return 3; }
 extern "C" const char* accbpg_last_error(void) { return g_err; }
 
 namespace accbpg {

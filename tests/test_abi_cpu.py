@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), "missing export " + name
     assert sorted(_lib.EXPORTS) == names, "ctypes table and header disagree"
-    assert lib.accbpg_abi_version() == 2
+    assert lib.accbpg_abi_version() == 3
 
 
 def test_missing_library_fails_loudly(monkeypatch):
