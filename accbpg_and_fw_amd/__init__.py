@@ -17,7 +17,7 @@ from .functions_lmo import lmo_simplex
 from .D_opt_alg import D_opt_FW, D_opt_FW_away
 from .applications import D_opt_design, D_opt_libsvm, D_opt_KYinit, Poisson_regrL1, Poisson_regrL2
 from .utils import load_libsvm_file
-from .batched import DOptimalBatch, ABPG_batch, ABPG_gain_batch, solve_batch, solve_instances
+from .batched import DOptimalBatch, BPG_batch, ABPG_batch, ABPG_gain_batch, solve_batch, solve_instances
 
 __all__ = ["RSmoothFunction", "DOptimalObj", "PoissonRegression", "LegendreFunction", "BurgEntropy",
            "BurgEntropyL1", "BurgEntropyL2", "BurgEntropySimplex", "Poisson_regrL1", "Poisson_regrL2",

@@ -291,6 +291,80 @@ def ABPG_batch(batch, h, L, x0, gamma, maxitrs, epsilon=1e-14, theta_eq=False, r
             return stop.value
 
 
+def BPG_batch_steps(batch, h, L, x0, maxitrs, epsilon=1e-14, linesearch=True, ls_ratio=1.2):
+    """BPG (accbpg/algorithms.py:11-72) on the K instances of a ``DOptimalBatch`` in lock-step per ORACLE PASS: one
+    evaluation of (f, grad) at the iterates of all running instances, then one prox + one trial value per pass of the
+    backtracking search, for the instances that are still searching.  L is carried per instance (divided by ls_ratio
+    before each search, :51; multiplied after each failed test, :54); an instance stops when |F[k] - F[k-1]| <
+    epsilon (:66) and drops out of the later launches.  Yields k after every outer iteration; returns, per instance,
+    BPG's (x, F, Ls, T) -- bit-identical to ``BPG(batch.instance(i), h, L, x0, ...)``."""
+    K, n = batch.K, batch.n
+    t_start = time.time()
+    x0d, as_numpy = to_dev(x0)
+    X = x0d.reshape(1, -1).repeat(K, 1).contiguous() if x0d.dim() == 1 else x0d.clone().contiguous()
+    assert X.shape == (K, n)
+    F = np.zeros((K, maxitrs)); Ls = np.ones((K, maxitrs)) * L; T = np.zeros((K, maxitrs))
+    Lc = [L] * K
+    active = [True] * K
+    last = [-1] * K
+    result_x = [None] * K
+    eps_prox = getattr(h, "eps", 1e-8)
+    for k in range(maxitrs):
+        if not any(active):
+            break
+        fx, Gr = batch.func_grad(X, 2, active)                              # :46
+        now = time.time() - t_start
+        for i in range(K):
+            if active[i]:
+                F[i, k] = fx[i] + h.extra_Psi(None)                         # :47
+                T[i, k] = now
+        Xt = torch.empty(K, n, dtype=torch.float64, device=batch.device)    # rows are written by the passes that need them
+        if linesearch:
+            for i in range(K):
+                if active[i]:
+                    Lc[i] = Lc[i] / ls_ratio                                # :51
+            search = list(active)
+            while any(search):                                              # one pass = one trial per searching instance
+                batch.prox(X, Gr, Lc, eps_prox, search, out=Xt)             # :52 / :55
+                terms = batch.ls_terms(Gr, Xt, X, None, None, search)       # <g, x+ - x>, D(x+, x)
+                ft = batch.func_grad(Xt, 0, search)                         # :53
+                for i in range(K):
+                    if search[i]:
+                        if ft[i] > fx[i] + terms[i, 0] + Lc[i] * terms[i, 1]:
+                            Lc[i] = Lc[i] * ls_ratio                        # :54
+                        else:
+                            search[i] = False
+        else:
+            batch.prox(X, Gr, Lc, eps_prox, active, out=Xt)                 # :58
+        for i in range(K):
+            if not active[i]:
+                continue
+            Ls[i, k] = Lc[i]
+            last[i] = k
+            if k > 0 and abs(F[i, k] - F[i, k - 1]) < epsilon:              # :66
+                active[i] = False
+                result_x[i] = Xt[i].clone()
+        X = Xt
+        yield k
+    out = []
+    for i in range(K):
+        xi = result_x[i] if result_x[i] is not None else X[i].clone()
+        xi = xi.cpu().numpy() if as_numpy else xi
+        e = last[i] + 1
+        out.append((xi, F[i, :e].copy(), Ls[i, :e].copy(), T[i, :e].copy()))
+    return out
+
+
+def BPG_batch(batch, h, L, x0, maxitrs, epsilon=1e-14, linesearch=True, ls_ratio=1.2):
+    """Drain ``BPG_batch_steps``: list of (x, F, Ls, T), one per instance."""
+    gen = BPG_batch_steps(batch, h, L, x0, maxitrs, epsilon, linesearch, ls_ratio)
+    while True:
+        try:
+            next(gen)
+        except StopIteration as stop:
+            return stop.value
+
+
 def solve_instances(make_problem, num_instances, solver, world=1, rank=0, threads=None, concurrent=True,
                     group=None, **solver_kwargs):
     """BASELINE config 4 end to end: deal `num_instances` independent problems to the ranks

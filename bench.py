@@ -333,7 +333,7 @@ def main():
         and float(m) * n <= 2.0 * 2048 * 32768
     total = args.warmup + args.steps
     # (the lock-step batch times its kernels over `steps` further steps behind the driver-timed region)
-    horizon = max(total + args.steps, args.steady_start + args.steady_iters + args.steps if steady else 0) + 2
+    horizon = total + args.steps + (max(0, args.steady_start - total) + args.steady_iters if steady else 0) + 2
 
     def make_gen(ff, hh, length):
         if args.workload == "abpg_gain":
@@ -345,15 +345,19 @@ def main():
     batch = None
     lockstep = None
     objs = [f]
-    if ipg > 1 and args.workload in ("abpg", "abpg_gain") and not shard and not args.host_threads:
+    if ipg > 1 and args.workload in ("bpg", "abpg", "abpg_gain") and not shard and not args.host_threads:
         # BASELINE config 4: the instances of this GPU advance in lock-step, one launch per kernel family for all of
         # them (accbpg_dopt_batch_*); results are bit-identical to solving them one after the other
-        from accbpg_and_fw_amd.batched import ABPG_batch_steps, ABPG_gain_batch_steps, DOptimalBatch
+        from accbpg_and_fw_amd.batched import ABPG_batch_steps, ABPG_gain_batch_steps, BPG_batch_steps, DOptimalBatch
         lockstep = DOptimalBatch([f.V_dev] + [make_instance(m, n, 1 + idx, device) for idx in mine[1:]])
         objs = [lockstep]
         prof_objs = [lockstep]
         if args.workload == "abpg":
             gen = ABPG_batch_steps(lockstep, acc.BurgEntropySimplex(), 1.0, x0, 2, horizon, overlap=overlap)
+        elif args.workload == "bpg":
+            # epsilon=0: BPG's |F[k]-F[k-1]| stopping test never fires, so the steady-state region below still has
+            # running instances at this small shape (the timed region itself ends long before the test would fire)
+            gen = BPG_batch_steps(lockstep, acc.BurgEntropySimplex(), 1.0, x0, horizon, epsilon=0.0)
         else:
             gen = ABPG_gain_batch_steps(lockstep, acc.BurgEntropySimplex(), 1.0, x0, 2, horizon, overlap=overlap)
 

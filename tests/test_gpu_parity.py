@@ -1114,6 +1114,41 @@ def test_lockstep_abpg_gain_matches_sequential(acc, shape, K, opts):
     assert len(patterns) > 1 or K == 1                          # the instances did not all search alike
 
 
+@pytest.mark.parametrize("shape,K,opts", [
+    ((256, 1024), 5, dict()),
+    ((256, 1024), 3, dict(linesearch=False)),
+    ((256, 2048), 4, dict(ls_ratio=1.5)),
+    ((512, 8192), 4, dict())])
+def test_lockstep_bpg_matches_sequential(acc, O, shape, K, opts):
+    """BPG over a batch (accbpg/algorithms.py:11-72 per instance): one (f, grad) launch for all running instances,
+    then one prox + one trial value per pass of the backtracking search for the instances still searching.  Every
+    instance's run -- iterates, F and the L_k sequence with its retries -- is bit-identical to BPG on that instance
+    alone, the instances do search differently, and one instance's F agrees with the oracle-backed solver."""
+    from accbpg_and_fw_amd.batched import BPG_batch, DOptimalBatch
+    m, n = shape
+    Vs = [gaussian_design(m, n, 500 + 11 * i) for i in range(K)]
+    batch = DOptimalBatch(Vs)
+    assert batch.fused
+    h = acc.BurgEntropySimplex()
+    x0 = np.ones(n) / n
+    iters = 40
+    outs = BPG_batch(batch, h, 1.0, x0, iters, **opts)
+    assert len(outs) == K
+    patterns = set()
+    for i in range(K):
+        ref = acc.BPG(batch.instance(i), h, 1.0, x0, maxitrs=iters, verbose=False, **opts)
+        for got, want in zip(outs[i][:-1], ref[:-1]):
+            np.testing.assert_array_equal(got, want)
+        patterns.add(tuple(ref[2]))
+    if opts.get("linesearch", True):
+        assert len(patterns) > 1                                 # the instances did not all search alike
+    # one instance against the CPU restatement of the solver (same L_k decisions, F to rounding)
+    xo, Fo, Lo, To = O.BPG(O.DOptOracle(Vs[0]), O.BurgSimplexOracle(), 1.0, x0, iters, **opts)
+    np.testing.assert_array_equal(outs[0][2], Lo)
+    np.testing.assert_allclose(outs[0][1], Fo, rtol=1e-10)
+    assert np.max(np.abs(outs[0][0] - xo)) < 1e-12
+
+
 def test_batch_size_limit_is_a_clean_error(acc):
     """A batch holds at most ACCBPG_BATCH_MAX = 64 instances (the active set travels as a fixed-size kernel argument):
     one more is refused at creation with ACCBPG_ERR_ARG -> ValueError, 64 are accepted and evaluate."""
