@@ -221,11 +221,12 @@ __device__ __forceinline__ void gram_streamk_glds_body(
                 continue;
             }
         }
-        t.glds_setup_A(V, ldv, row0);
-        t.glds_setup_B_kc(V, ldv, col0);
+        constexpr int PAIR = (GV & 256) ? 4 : (GV & 128) ? 2 : 1;   // loads of the k-loop per M0 write (mfma_tile.hpp: glds16_run*)
+        t.template glds_setup_A<PAIR>(V, ldv, row0);
+        t.template glds_setup_B_kc<PAIR>(V, ldv, col0);
         auto issue = [&](int64_t ks, int buf) {
             double* st = lds + buf * T::G_STAGE;
-            t.glds_issue(ks * BK, ks * BK, st);
+            t.template glds_issue<PAIR>(ks * BK, ks * BK, st);
             t.glds_x(x, ks * BK, st);
         };
         __builtin_amdgcn_s_barrier();                           // previous segment's readers are done
@@ -290,7 +291,9 @@ __device__ __forceinline__ void gram_streamk_glds_body(
                             constexpr int lp = PB ? q - 8 : (((q & 1) == 0) ? (q >> 1) : -1);   // load slot behind this pair
                             if constexpr (g == 0 && lp >= 0 && !(GV & 1)) {
                                 constexpr int p0 = 2 * lp;
-                                if constexpr (p0 < NP) t.glds_issue_range(k2, k2, nst, p0, p0 + 2 < NP ? p0 + 2 : NP);
+                                if constexpr (PAIR == 4) {
+                                    if constexpr (p0 < NP && p0 % 4 == 0) t.template glds_issue_range<4>(k2, k2, nst, p0, p0 + 4);
+                                } else if constexpr (p0 < NP) t.template glds_issue_range<PAIR>(k2, k2, nst, p0, p0 + 2 < NP ? p0 + 2 : NP);
                                 if constexpr (p0 == NP || (p0 + 1 == NP)) t.glds_x(x, k2, nst);
                             }
                         } else {
@@ -370,7 +373,7 @@ __device__ __forceinline__ void gram_streamk_glds_body(
     }
 }
 
-constexpr int GRAM_GV = 96;     // schedule of the production Gram kernel: dealt out (32), placement B (64)
+constexpr int GRAM_GV = 224;    // schedule of the production Gram kernel: dealt out (32), placement B (64), loads two to an M0 write (128)
 template <class T, int GV = 0>
 __global__ __launch_bounds__(NTHREADS, 1) void gram_streamk_glds_kernel(
     const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n, const double* __restrict__ x,
@@ -576,6 +579,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void colnorm_kernel(
 }
 
 // Direct-to-LDS version of the gradient kernel for interior sizes.
+// CV: 32 = dealt-out schedule, 64 = its placement B (both development variants), 256 = loads four to an M0 write.
+constexpr int COLNORM_CV = 256; // the production gradient kernel: block schedule, loads four to an M0 write
 template <class T, int CV = 0>
 __device__ __forceinline__ void colnorm_glds_body(
     const double* __restrict__ W, int64_t ldw, const double* __restrict__ V, int64_t ldv, int64_t m, int64_t n,
@@ -597,10 +602,11 @@ __device__ __forceinline__ void colnorm_glds_body(
         const int64_t ksteps = (row0 + T::BM) / BK;             // W is lower triangular
         const int64_t klast = ksteps - 1;
         t.zero();
-        t.glds_setup_A(W, ldw, row0);
-        t.glds_setup_B_km(V, ldv, col0);
+        constexpr int RUN = (CV & 256) ? 4 : 1;                 // loads per M0 write (mfma_tile.hpp: glds16_run4)
+        t.template glds_setup_A<RUN>(W, ldw, row0);
+        t.template glds_setup_B_km<RUN>(V, ldv, col0);
         auto issue = [&](int64_t ks, int buf) {
-            t.glds_issue(ks * BK, ks * BK * ldv, lds + buf * T::G_STAGE);
+            t.template glds_issue<RUN>(ks * BK, ks * BK * ldv, lds + buf * T::G_STAGE);
         };
         __builtin_amdgcn_s_barrier();
         issue(0, 0);
@@ -686,11 +692,11 @@ __device__ __forceinline__ void colnorm_glds_body(
             t.template read_frag_g<1, false>(st, 1);
             __builtin_amdgcn_sched_barrier(0);
             t.template mma_row<0>(0, mi_lo);
-            t.glds_issue_range(k2, k2 * ldv, nst, 0, P1);
+            t.template glds_issue_range<RUN>(k2, k2 * ldv, nst, 0, P1);
             t.template mma_row<0>(1, mi_lo);
-            t.glds_issue_range(k2, k2 * ldv, nst, P1, P2);
+            t.template glds_issue_range<RUN>(k2, k2 * ldv, nst, P1, P2);
             t.template mma_row<0>(2, mi_lo);
-            t.glds_issue_range(k2, k2 * ldv, nst, P2, NP);
+            t.template glds_issue_range<RUN>(k2, k2 * ldv, nst, P2, NP);
             t.template mma_row<0>(3, mi_lo);
             __builtin_amdgcn_sched_barrier(0);
             t.template read_frag_g<0, false>(st, 2);
@@ -755,7 +761,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void colnorm_glds_batch_kernel(
     double* __restrict__ outbase, int64_t ldo, double sign) {
     const int inst = act.idx[blockIdx.y];
     const BatchInst bi = bt[inst];
-    colnorm_glds_body<T>(bi.Wbuf, ldw, bi.V, ldv, m, n, outbase + (int64_t)inst * ldo, sign);
+    colnorm_glds_body<T, COLNORM_CV>(bi.Wbuf, ldw, bi.V, ldv, m, n, outbase + (int64_t)inst * ldo, sign);
 }
 
 // =========================================================================================
@@ -2509,22 +2515,25 @@ int build_plans(accbpg_dopt* h) {
     ACC_TRY(set_lds(chol_step_kernel, CHOL_LDS_BYTES));
     ACC_TRY(set_lds(chol_syrk_kernel, SYRK_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>>, TileBig<false, false>::G_LDS_BYTES));
-    ACC_TRY(set_lds(colnorm_glds_kernel<TileBig<true, false>>, TileBig<true, false>::G_LDS_BYTES + 4 * 128 * 8));
-    ACC_TRY(set_lds(colnorm_glds_kernel<TileBig<true, false>, 32>, TileBig<true, false>::G_LDS_BYTES + 4 * 128 * 8));
+    ACC_TRY(set_lds(colnorm_glds_kernel<TileBig<true, false>, COLNORM_CV>, TileBig<true, false>::G_LDS_BYTES + 4 * 128 * 8));
+    ACC_TRY(set_lds(colnorm_glds_kernel<TileBig<true, false>, COLNORM_CV ^ 256>, TileBig<true, false>::G_LDS_BYTES + 4 * 128 * 8));
     ACC_TRY(set_lds(colnorm_glds_kernel<TileBig<true, false>, 96>, TileBig<true, false>::G_LDS_BYTES + 4 * 128 * 8));
     ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>, 32>, TileBig<false, false>::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>, 96>, TileBig<false, false>::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>, GRAM_GV>, TileBig<false, false>::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>, GRAM_GV ^ 128>, TileBig<false, false>::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>, (GRAM_GV ^ 128) | 256>, TileBig<false, false>::G_LDS_BYTES));
     ACC_TRY(set_lds(gemm_big_kernel<TileBig<true>>, TileBig<true>::LDS_BYTES));
     ACC_TRY(set_lds(gemm_big_kernel<TileBig<false>>, TileBig<false>::LDS_BYTES));
     return ACCBPG_OK;
 }
 
 template <class T>
-static void gram_launch_t(accbpg_dopt* h, const double* x, double* gram) {
+static int gram_launch_t(accbpg_dopt* h, const double* x, double* gram) {
     if constexpr (!T::EDGE && T::BM == 256) {
         if (h->use_glds || h->has_duals) {
-            // production: the dealt-out schedule, placement B (GRAM_GV); the development switch selects placement A (1)
-            // or the block schedule of round 2 (3) -- all three give bit-identical results.
+            // production: the dealt-out schedule, placement B, loads two to an M0 write (GRAM_GV); the development switch
+            // selects one load per M0 write through the builtin (1: round 3's first form), four to an M0 write (2), or
+            // the block schedule of round 2 (3) -- all give bit-identical results.
             // Long rows (gram_chunks > 1): one launch per column block of V, each adding its Gram matrix to G.
             const int64_t nc = h->gram_chunks > 1 ? h->gram_nc : h->n;
             for (int c = 0; c < h->gram_chunks; ++c) {
@@ -2535,31 +2544,37 @@ static void gram_launch_t(accbpg_dopt* h, const double* x, double* gram) {
                 const int all_slabs = h->gram_chunks > 1 ? 1 : 0;   // (the plan of a chunked handle lists every segment)
                 prof_begin(h, PROF_GRAM);
                 if (h->kern_variant == 1)
-                    gram_streamk_glds_kernel<T, 32><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
+                    gram_streamk_glds_kernel<T, GRAM_GV ^ 128><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
                         Vc, ldc, h->m, nc, xc, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m, all_slabs);
                 else if (h->kern_variant == 3)
                     gram_streamk_glds_kernel<T, 0><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
                         Vc, ldc, h->m, nc, xc, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m, all_slabs);
+                else if (h->kern_variant == 2)
+                    gram_streamk_glds_kernel<T, (GRAM_GV ^ 128) | 256><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
+                        Vc, ldc, h->m, nc, xc, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m, all_slabs);
                 else
                     gram_streamk_glds_kernel<T, GRAM_GV><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
                         Vc, ldc, h->m, nc, xc, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m, all_slabs);
+                ACC_HIP(hipGetLastError());                      // (here: the launch behind it would answer "success")
                 prof_end(h, PROF_GRAM);
                 prof_begin(h, PROF_GRAMFIX);
                 gram_fixup_kernel<T><<<h->ntiles * 2 * T::MI * FIX_PJ, NTHREADS, 0, h->stream>>>(
                     h->tiles, h->gram_cstart, h->gram_contrib, h->gram_nslot, h->slabs, gram, h->m, h->m, beta);
                 prof_end(h, PROF_GRAMFIX);
             }
-            return;
+            return ACCBPG_OK;
         }
     }
     prof_begin(h, PROF_GRAM);
     gram_streamk_kernel<T><<<h->gram_grid, NTHREADS, T::LDS_BYTES, h->stream>>>(
         h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m, h->vec_ok);
+    ACC_HIP(hipGetLastError());
     prof_end(h, PROF_GRAM);
     prof_begin(h, PROF_GRAMFIX);
     gram_fixup_kernel<T><<<h->ntiles * 2 * T::MI * FIX_PJ, NTHREADS, 0, h->stream>>>(h->tiles, h->gram_cstart, h->gram_contrib, h->gram_nslot,
                                                                 h->slabs, gram, h->m, h->m, 0.0);
     prof_end(h, PROF_GRAMFIX);
+    return ACCBPG_OK;
 }
 
 // timing ablations of the Gram kernel (big interior tile only); returns average ms over `iters`
@@ -2596,6 +2611,8 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
             case 25: ACC_LAUNCH_G(102); break;    /* dealt-out, loads only (no barrier, no reads) */
             case 26: ACC_LAUNCH_G(101); break;    /* dealt-out, barrier only (no loads, no reads) */
             case 27: ACC_LAUNCH_G(99); break;     /* dealt-out, reads only (no loads, no barrier) */
+            case 28: ACC_LAUNCH_G(224); break;    /* dealt-out, loads two to an M0 write */
+            case 29: ACC_LAUNCH_G(352); break;    /* dealt-out, loads four to an M0 write */
             case 0: ACC_LAUNCH_VAR(0); break;
             case 1: ACC_LAUNCH_VAR(1); break;
             case 2: ACC_LAUNCH_VAR(2); break;
@@ -2621,6 +2638,8 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
     ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 102>, T::G_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 103>, T::G_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 104>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 224>, T::G_LDS_BYTES));
+    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 352>, T::G_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 1>, T::LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 2>, T::LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 3>, T::LDS_BYTES));
@@ -2650,12 +2669,12 @@ int launch_gram(accbpg_dopt* h, const double* x, double* gram) {
     }
     if (h->big) {
         const bool interior = h->vec_ok && xal && (h->m % 256 == 0) && (h->n % BK == 0);
-        if (interior) gram_launch_t<TileBig<false, false>>(h, x, gram);
-        else gram_launch_t<TileBig<false, true>>(h, x, gram);
+        if (interior) ACC_TRY((gram_launch_t<TileBig<false, false>>(h, x, gram)));
+        else ACC_TRY((gram_launch_t<TileBig<false, true>>(h, x, gram)));
     } else {
         const bool interior = h->vec_ok && xal && (h->m % 64 == 0) && (h->n % BK == 0);
-        if (interior) gram_launch_t<TileSmall<false, false>>(h, x, gram);
-        else gram_launch_t<TileSmall<false, true>>(h, x, gram);
+        if (interior) ACC_TRY((gram_launch_t<TileSmall<false, false>>(h, x, gram)));
+        else ACC_TRY((gram_launch_t<TileSmall<false, true>>(h, x, gram)));
     }
     ACC_HIP(hipGetLastError());
     return ACCBPG_OK;
@@ -2823,13 +2842,13 @@ int launch_colnorm(accbpg_dopt* h, const double* W, double* out, double sign) {
         if (interior && h->use_glds) {
             using T = TileBig<true, false>;
             if (h->kern_variant == 1)
-                colnorm_glds_kernel<T, 32><<<(int)(h->n / T::BN), NTHREADS, T::G_LDS_BYTES + 4 * T::BN * 8, h->stream>>>(
+                colnorm_glds_kernel<T, COLNORM_CV ^ 256><<<(int)(h->n / T::BN), NTHREADS, T::G_LDS_BYTES + 4 * T::BN * 8, h->stream>>>(
                     W, h->m, h->V, h->ldv, h->m, h->n, out, sign);
             else if (h->kern_variant == 2)
                 colnorm_glds_kernel<T, 96><<<(int)(h->n / T::BN), NTHREADS, T::G_LDS_BYTES + 4 * T::BN * 8, h->stream>>>(
                     W, h->m, h->V, h->ldv, h->m, h->n, out, sign);
             else
-                colnorm_glds_kernel<T><<<(int)(h->n / T::BN), NTHREADS, T::G_LDS_BYTES + 4 * T::BN * 8, h->stream>>>(
+                colnorm_glds_kernel<T, COLNORM_CV><<<(int)(h->n / T::BN), NTHREADS, T::G_LDS_BYTES + 4 * T::BN * 8, h->stream>>>(
                     W, h->m, h->V, h->ldv, h->m, h->n, out, sign);
         } else if (interior) colnorm_launch_t<TileBig<true, false>>(h, W, out, sign, vw);
         else colnorm_launch_t<TileBig<true, true>>(h, W, out, sign, vw);

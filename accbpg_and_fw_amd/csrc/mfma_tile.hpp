@@ -266,6 +266,36 @@ struct Tile {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
+    // NPK pieces that are neighbours in the LDS image behind ONE write of M0: the instruction's immediate offset moves
+    // the LDS destination AND the global source, so piece j of such a run has its lane offset set up j KiB low
+    // (glds_setup_*<NPK>).  Takes the scalar work per load (M0 write + its wait state) and the copy of the lane offset
+    // that the builtin form needs out of the k-step.  `l0` = LDS byte address of the wave's first piece, OFF = bytes from
+    // there.  The "m0" clobber is REQUIRED: without it the compiler moves the M0 write of one of its own LDS-DMA loads (the
+    // x piece) above such a statement and its load then lands where this statement pointed M0.  (clang warns that a
+    // clobber of a reserved register is not saved and restored -- nothing needs it to be: the compiler writes M0 before
+    // every use; with the clobber it also orders those writes behind the statement.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    template <int OFF>
+    static __device__ __forceinline__ void glds16_run2(const char* __restrict__ base, uint32_t o0, uint32_t o1, uint32_t l0) {
+        asm volatile("s_add_u32 m0, %2, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024"
+                     :: "v"(o0), "v"(o1), "s"(l0), "s"(base), "i"(OFF) : "memory", "scc", "m0");
+    }
+    template <int OFF>
+    static __device__ __forceinline__ void glds16_run4(const char* __restrict__ base, uint32_t o0, uint32_t o1, uint32_t o2,
+                                                       uint32_t o3, uint32_t l0) {
+        asm volatile("s_add_u32 m0, %4, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %5\n\tglobal_load_lds_dwordx4 %1, %5 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %2, %5 offset:2048\n\tglobal_load_lds_dwordx4 %3, %5 offset:3072"
+                     :: "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(l0), "s"(base), "i"(OFF) : "memory", "scc", "m0");
+    }
+#pragma clang diagnostic pop
+    static __device__ __forceinline__ uint32_t lds_addr(const double* p) {
+        return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+    }
+    static constexpr int G_PAIR_LOW = 1024;
+    // 1-KiB piece of the image that piece p of wave `wave` fills: dealt round the waves, or (runs) np consecutive ones
+    template <int NPK>
+    static __device__ __forceinline__ int glds_piece(int wave, int p, int np) { return NPK > 1 ? wave * np + p : wave + 4 * p; }
     // per-lane BYTE offsets of the pieces this wave moves, relative to the uniform base pointers of k-step 0
     // (set once per tile segment).  A k-step adds a scalar to the base only, so the load takes the
     // "scalar base + 32-bit lane offset" addressing form and needs no vector address arithmetic.
@@ -273,41 +303,54 @@ struct Tile {
     uint32_t gob[G_NB];
     const char* gbase_a;
     const char* gbase_b;
+    template <int NPK = 1>
     __device__ __forceinline__ void glds_setup_A(const double* __restrict__ A, int64_t lda, int64_t row0) {
+        static_assert(G_NA % NPK == 0, "pieces go out in whole runs");
         const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         gbase_a = reinterpret_cast<const char*>(A + row0 * lda);
 #pragma unroll
         for (int p = 0; p < G_NA; ++p) {
-            const int q = wave + 4 * p;                          // 1-KiB piece = rows 8q .. 8q+7
+            const int q = glds_piece<NPK>(wave, p, G_NA);        // 1-KiB piece = rows 8q .. 8q+7
             const int row = 8 * q + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
-            goa[p] = (uint32_t)(((int64_t)row * lda + 2 * c) * 8);
+            // (piece j of a run has q >= j, so its offset is at least 8j rows = 64j * lda bytes >= j KiB: lda >= BK)
+            goa[p] = (uint32_t)(((int64_t)row * lda + 2 * c) * 8) - (p % NPK) * G_PAIR_LOW;
         }
     }
+    template <int NPK = 1>
     __device__ __forceinline__ void glds_setup_B_kc(const double* __restrict__ B, int64_t ldb, int64_t col0) {
+        static_assert(G_NB % NPK == 0, "pieces go out in whole runs");
         const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         gbase_b = reinterpret_cast<const char*>(B + col0 * ldb);
 #pragma unroll
         for (int p = 0; p < G_NB; ++p) {
-            const int q = wave + 4 * p;
+            const int q = glds_piece<NPK>(wave, p, G_NB);
             const int row = 8 * q + (lane >> 3);
             const int c = (lane & 7) ^ ((row >> 1) & 7);
-            gob[p] = (uint32_t)(((int64_t)row * ldb + 2 * c) * 8);
+            gob[p] = (uint32_t)(((int64_t)row * ldb + 2 * c) * 8) - (p % NPK) * G_PAIR_LOW;
         }
     }
+    template <int NPK = 1>
     __device__ __forceinline__ void glds_setup_B_km(const double* __restrict__ B, int64_t ldb, int64_t col0) {
         static_assert(!BKM || BN == 128, "one 1-KiB piece per k-row");
+        static_assert(G_NB % NPK == 0, "pieces go out in whole runs");
         const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         gbase_b = reinterpret_cast<const char*>(B + col0);
 #pragma unroll
         for (int p = 0; p < G_NB; ++p) {
-            const int kr = wave + 4 * p;                         // k-row of the tile
+            const int kr = glds_piece<NPK>(wave, p, G_NB);       // k-row of the tile
             const int c = lane ^ (8 * (kr & 1));                 // source chunk (2 columns) for LDS chunk `lane`
-            gob[p] = (uint32_t)(((int64_t)kr * ldb + 2 * c) * 8);
+            // (piece j of a run has kr >= j, so its offset is at least j rows = 8j * ldb bytes >= j KiB: ldb >= BN)
+            gob[p] = (uint32_t)(((int64_t)kr * ldb + 2 * c) * 8) - (p % NPK) * G_PAIR_LOW;
         }
     }
     // issue the pieces of one k-step: ka / kb = element offsets of that step in A / B
+    template <int NPK = 1>
     __device__ __forceinline__ void glds_issue(int64_t ka, int64_t kb, double* __restrict__ stage) const {
+        if constexpr (NPK > 1) {
+            glds_issue_range<NPK>(ka, kb, stage, 0, G_NA + G_NB);
+            return;
+        }
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const char* ba = gbase_a + ka * 8;
         const char* bb = gbase_b + kb * 8;
@@ -327,11 +370,30 @@ struct Tile {
         }
     }
     // pieces [p0, p1) of the combined list (A pieces first, then B pieces) of one k-step
+    template <int NPK = 1>
     __device__ __forceinline__ void glds_issue_range(int64_t ka, int64_t kb, double* __restrict__ stage, int p0,
                                                      int p1) const {
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const char* ba = gbase_a + ka * 8;
         const char* bb = gbase_b + kb * 8;
+        if constexpr (NPK > 1) {
+            // (p0, p1 multiples of NPK: a range is whole runs)
+            const uint32_t la = lds_addr(stage + wave * G_NA * 128), lb = lds_addr(stage + G_A + wave * G_NB * 128);
+            static_for<0, (G_NA + G_NB) / NPK>([&](auto rtag) {
+                constexpr int p = decltype(rtag)::value * NPK;
+                if (p >= p0 && p + NPK <= p1) {
+                    if constexpr (p < G_NA) {
+                        if constexpr (NPK == 2) glds16_run2<p * 1024>(ba, goa[p], goa[p + 1], la);
+                        else glds16_run4<p * 1024>(ba, goa[p], goa[p + 1], goa[p + 2], goa[p + 3], la);
+                    } else {
+                        constexpr int pb = p - G_NA;
+                        if constexpr (NPK == 2) glds16_run2<pb * 1024>(bb, gob[pb], gob[pb + 1], lb);
+                        else glds16_run4<pb * 1024>(bb, gob[pb], gob[pb + 1], gob[pb + 2], gob[pb + 3], lb);
+                    }
+                }
+            });
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < G_NA + G_NB; ++p)
             if (p >= p0 && p < p1) {

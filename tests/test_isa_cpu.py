@@ -19,9 +19,9 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 # mangled-name fragments of the production kernels -> scratch bytes they are allowed (their state when tuned)
 KERNELS = {
-    "gram_streamk_glds_kernelINS_4TileILi256ELi128ELi64ELi128ELb0ELb0EEELi96EEE": 0,
+    "gram_streamk_glds_kernelINS_4TileILi256ELi128ELi64ELi128ELb0ELb0EEELi224EEE": 0,
     "gram_streamk_glds_batch_kernel": 0,
-    "colnorm_glds_kernelINS_4TileILi256ELi128ELi64ELi128ELb1ELb0EEELi0EEE": 32,
+    "colnorm_glds_kernelINS_4TileILi256ELi128ELi64ELi128ELb1ELb0EEELi256EEE": 32,
     "colnorm_glds_batch_kernel": 32,
 }
 
@@ -64,3 +64,30 @@ def test_main_loop_keeps_its_accumulators(asm, fragment):
     assert moves == 0 and spills == 0, "%s: %d accumulator-file moves, %d scratch accesses in the k-step loop" % (fragment, moves, spills)
     total_moves = sum(l.strip().startswith("v_accvgpr_read") for l in body)
     assert total_moves <= 600, (fragment, total_moves)          # epilogues read the accumulators once
+
+
+@pytest.mark.parametrize("fragment", sorted(KERNELS))
+def test_compiler_m0_writes_reach_their_loads(asm, fragment):
+    """The hand-written load statements (mfma_tile.hpp: glds16_run2 / _run4) write M0 themselves.  Without their "m0"
+    clobber the compiler moved the M0 write of one of ITS LDS-DMA loads above such a statement, and that load landed where
+    the statement had pointed M0 (wrong Gram matrices, no fault).  So: between an M0 write the compiler emitted and the
+    LDS-DMA load it belongs to there may be no inline-asm statement that touches M0."""
+    body = [l.strip() for l in _kernel_lines(asm, fragment)]
+    in_asm, pending, runs = False, None, 0
+    for i, l in enumerate(body):
+        if l.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if l.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if in_asm:
+            if "m0" in l:
+                runs += 1
+                assert pending is None, "%s: asm statement writes M0 between the compiler's '%s' and its load" % (fragment, pending)
+            continue
+        if re.match(r"s_\w+\s+m0,", l):
+            pending = l
+        elif l.startswith("global_load_lds") or l.startswith("buffer_load") and " lds" in l:
+            pending = None
+    assert runs > 0, "%s: no hand-written load statement found -- the check above tested nothing" % fragment

@@ -1,7 +1,11 @@
 """A/B of the schedules of the direct-to-LDS Gram and gradient kernels in ONE process, interleaved rounds
 (cdna_hip_programming.md 5.4 rule 24): variant 0 = reads and multiplies issued as a block at every fragment-group
 boundary, 1 = dealt out between MFMA pairs (reads behind odd pairs, loads behind even pairs, barrier in the middle of the
-last group), 2 = dealt out with the reads early in the group and the barrier behind the first fragment row.
+last group; timing code 18, no longer in the table), 2 = dealt out with the reads early in the group and the barrier behind
+the first fragment row, one load per M0 write through the builtin; 3 / 4 = variant 2 with the loads of the k-loop two
+(production) / four to an M0 write.  The handle's switch, used for the bit-identity check and the gradient kernel's
+timings: Gram 0 = production, 1 = builtin loads, 2 = four to an M0 write, 3 = block schedule; gradient kernel 0 =
+production (block schedule, four loads to an M0 write), 1 = builtin loads, 2 = dealt out.
 Checks first that value and gradient are bit-identical under every variant."""
 import argparse
 import ctypes as C
@@ -43,20 +47,20 @@ def main():
     print("bit-identical:", same, flush=True)
     out = {"shape": [args.m, args.n], "bit_identical": same, "gram_ms": {}, "grad_ms": {}}
     ms = C.c_double(0.0)
-    codes = {0: 10, 1: 18, 2: 19}
+    codes = {0: 10, 2: 19, 3: 28, 4: 29}
     for rnd in range(args.rounds):
         for v, code in codes.items():
             _lib.check(lib.accbpg_debug_gram_variant(f._h, _ptr(x), code, args.iters, C.byref(ms)), "gram variant")
             out["gram_ms"].setdefault(v, []).append(ms.value)
-        for v in codes:
-            lib.accbpg_debug_chol_variant(f._h, v << 30)
+        for v in (0, 1, 2):
+            lib.accbpg_debug_chol_variant(f._h, v << 30)             # gradient kernel: 0 production, 1 builtin loads, 2 dealt out
             f.profile(True)
             for _ in range(args.iters):
                 f.func_grad(x, 1)
             tot, cnt = f.profile_read()["grad"]
             f.profile(False)
             out["grad_ms"].setdefault(v, []).append(tot / cnt)
-        print(rnd, {v: round(out["gram_ms"][v][-1], 4) for v in codes}, {v: round(out["grad_ms"][v][-1], 4) for v in codes},
+        print(rnd, {v: round(out["gram_ms"][v][-1], 4) for v in codes}, {v: round(out["grad_ms"][v][-1], 4) for v in (0, 1, 2)},
               flush=True)
     lib.accbpg_debug_chol_variant(f._h, 0)
     for key in ("gram_ms", "grad_ms"):
