@@ -8,6 +8,7 @@
 //   :57  np.linalg.solve(HXHT, H)    -> W = L^-1 (trtri_diag + merge GEMMs), Y = W V never stored
 //   :58  -sum(H * HXHTinvH, axis=0)  -> -colsum(Y*Y) fused into the product (colnorm_kernel)
 #include <mutex>
+#include <unordered_map>
 #include <type_traits>
 
 #include "internal.h"
@@ -2131,6 +2132,28 @@ static int set_lds(K kernel, int bytes) {
     return ACCBPG_OK;
 }
 
+// The kernels with variants (schedules, ablations) raise their limit at the launch site, the first time the instantiation
+// is launched: on this runtime a launch that asks for more dynamic LDS than the kernel's limit reports NO error -- not from
+// the launch, not from hipGetLastError, not from a synchronize -- and leaves garbage (measured; a Gram variant that had
+// been left out of a list of set_lds calls went unnoticed until its results were compared).
+static int ensure_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, int> limit;
+    std::lock_guard<std::mutex> guard(mu);
+    auto it = limit.find(kernel);
+    if (it != limit.end() && it->second >= bytes) return ACCBPG_OK;
+    ACC_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    limit[kernel] = bytes;
+    return ACCBPG_OK;
+}
+// (a kernel name with template commas goes in parentheses)
+#define ACC_LAUNCH_LDS(kernel, grid, block, lds, stream, ...)                        \
+    do {                                                                             \
+        auto k__ = kernel;                                                           \
+        ACC_TRY(ensure_lds(reinterpret_cast<const void*>(k__), (int)(lds)));         \
+        k__<<<(grid), (block), (lds), (stream)>>>(__VA_ARGS__);                      \
+    } while (0)
+
 void prof_begin(accbpg_dopt* h, ProfKind k) {
     if (!h->prof_on) return;
     ProfSlot& p = h->prof[k];
@@ -2514,14 +2537,6 @@ int build_plans(accbpg_dopt* h) {
     ACC_TRY(set_lds(gemm_ops_kernel<TileSmall<false>>, TileSmall<false>::LDS_BYTES));
     ACC_TRY(set_lds(chol_step_kernel, CHOL_LDS_BYTES));
     ACC_TRY(set_lds(chol_syrk_kernel, SYRK_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>>, TileBig<false, false>::G_LDS_BYTES));
-    ACC_TRY(set_lds(colnorm_glds_kernel<TileBig<true, false>, COLNORM_CV>, TileBig<true, false>::G_LDS_BYTES + 4 * 128 * 8));
-    ACC_TRY(set_lds(colnorm_glds_kernel<TileBig<true, false>, COLNORM_CV ^ 256>, TileBig<true, false>::G_LDS_BYTES + 4 * 128 * 8));
-    ACC_TRY(set_lds(colnorm_glds_kernel<TileBig<true, false>, 96>, TileBig<true, false>::G_LDS_BYTES + 4 * 128 * 8));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>, 32>, TileBig<false, false>::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>, GRAM_GV>, TileBig<false, false>::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>, GRAM_GV ^ 128>, TileBig<false, false>::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<TileBig<false, false>, (GRAM_GV ^ 128) | 256>, TileBig<false, false>::G_LDS_BYTES));
     ACC_TRY(set_lds(gemm_big_kernel<TileBig<true>>, TileBig<true>::LDS_BYTES));
     ACC_TRY(set_lds(gemm_big_kernel<TileBig<false>>, TileBig<false>::LDS_BYTES));
     return ACCBPG_OK;
@@ -2543,19 +2558,17 @@ static int gram_launch_t(accbpg_dopt* h, const double* x, double* gram) {
                 const double beta = c == 0 ? 0.0 : 1.0;
                 const int all_slabs = h->gram_chunks > 1 ? 1 : 0;   // (the plan of a chunked handle lists every segment)
                 prof_begin(h, PROF_GRAM);
+#define ACC_GRAM_ARGS Vc, ldc, h->m, nc, xc, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m, all_slabs
                 if (h->kern_variant == 1)
-                    gram_streamk_glds_kernel<T, GRAM_GV ^ 128><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
-                        Vc, ldc, h->m, nc, xc, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m, all_slabs);
+                    ACC_LAUNCH_LDS((gram_streamk_glds_kernel<T, GRAM_GV ^ 128>), h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream, ACC_GRAM_ARGS);
                 else if (h->kern_variant == 3)
-                    gram_streamk_glds_kernel<T, 0><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
-                        Vc, ldc, h->m, nc, xc, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m, all_slabs);
+                    ACC_LAUNCH_LDS((gram_streamk_glds_kernel<T, 0>), h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream, ACC_GRAM_ARGS);
                 else if (h->kern_variant == 2)
-                    gram_streamk_glds_kernel<T, (GRAM_GV ^ 128) | 256><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
-                        Vc, ldc, h->m, nc, xc, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m, all_slabs);
+                    ACC_LAUNCH_LDS((gram_streamk_glds_kernel<T, (GRAM_GV ^ 128) | 256>), h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream, ACC_GRAM_ARGS);
                 else
-                    gram_streamk_glds_kernel<T, GRAM_GV><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(
-                        Vc, ldc, h->m, nc, xc, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, gram, h->m, all_slabs);
-                ACC_HIP(hipGetLastError());                      // (here: the launch behind it would answer "success")
+                    ACC_LAUNCH_LDS((gram_streamk_glds_kernel<T, GRAM_GV>), h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream, ACC_GRAM_ARGS);
+#undef ACC_GRAM_ARGS
+                ACC_HIP(hipGetLastError());
                 prof_end(h, PROF_GRAM);
                 prof_begin(h, PROF_GRAMFIX);
                 gram_fixup_kernel<T><<<h->ntiles * 2 * T::MI * FIX_PJ, NTHREADS, 0, h->stream>>>(
@@ -2585,12 +2598,12 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
     hipEvent_t a, b;
     ACC_HIP(hipEventCreate(&a));
     ACC_HIP(hipEventCreate(&b));
-    auto launch = [&]() {
+    auto launch = [&]() -> int {
 #define ACC_LAUNCH_VAR(VV)                                                                                       \
     gram_streamk_kernel<T, VV><<<h->gram_grid, NTHREADS, T::LDS_BYTES, h->stream>>>(                             \
         h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, h->Tbuf, h->m, h->vec_ok)
 #define ACC_LAUNCH_G(GG)                                                                                         \
-    gram_streamk_glds_kernel<T, GG><<<h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream>>>(                      \
+    ACC_LAUNCH_LDS((gram_streamk_glds_kernel<T, GG>), h->gram_grid, NTHREADS, T::G_LDS_BYTES, h->stream,          \
         h->V, h->ldv, h->m, h->n, x, h->tiles, h->wg_ranges, h->kiters, h->gram_nslot, h->slabs, h->Tbuf, h->m, 0)
         switch (var) {
             case 10: ACC_LAUNCH_G(0); break;
@@ -2620,33 +2633,15 @@ int debug_gram_variant(accbpg_dopt* h, const double* x, int var, int iters, doub
             default: ACC_LAUNCH_VAR(4); break;
         }
 #undef ACC_LAUNCH_VAR
+        return ACCBPG_OK;
     };
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 1>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 2>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 3>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 4>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 8>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 7>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 16>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 32>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 96>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 97>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 98>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 99>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 100>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 101>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 102>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 103>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 104>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 224>, T::G_LDS_BYTES));
-    ACC_TRY(set_lds(gram_streamk_glds_kernel<T, 352>, T::G_LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 1>, T::LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 2>, T::LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 3>, T::LDS_BYTES));
     ACC_TRY(set_lds(gram_streamk_kernel<T, 4>, T::LDS_BYTES));
-    launch();
+    ACC_TRY(launch());
     ACC_HIP(hipEventRecord(a, h->stream));
-    for (int i = 0; i < iters; ++i) launch();
+    for (int i = 0; i < iters; ++i) ACC_TRY(launch());
     ACC_HIP(hipEventRecord(b, h->stream));
     ACC_HIP(hipEventSynchronize(b));
     float ms = 0.f;
@@ -2841,15 +2836,13 @@ int launch_colnorm(accbpg_dopt* h, const double* W, double* out, double sign) {
         const bool interior = vw && h->vec_ok && (h->m % 256 == 0) && (h->n % 128 == 0);
         if (interior && h->use_glds) {
             using T = TileBig<true, false>;
+            const int grid = (int)(h->n / T::BN), lds = T::G_LDS_BYTES + 4 * T::BN * 8;
             if (h->kern_variant == 1)
-                colnorm_glds_kernel<T, COLNORM_CV ^ 256><<<(int)(h->n / T::BN), NTHREADS, T::G_LDS_BYTES + 4 * T::BN * 8, h->stream>>>(
-                    W, h->m, h->V, h->ldv, h->m, h->n, out, sign);
+                ACC_LAUNCH_LDS((colnorm_glds_kernel<T, COLNORM_CV ^ 256>), grid, NTHREADS, lds, h->stream, W, h->m, h->V, h->ldv, h->m, h->n, out, sign);
             else if (h->kern_variant == 2)
-                colnorm_glds_kernel<T, 96><<<(int)(h->n / T::BN), NTHREADS, T::G_LDS_BYTES + 4 * T::BN * 8, h->stream>>>(
-                    W, h->m, h->V, h->ldv, h->m, h->n, out, sign);
+                ACC_LAUNCH_LDS((colnorm_glds_kernel<T, 96>), grid, NTHREADS, lds, h->stream, W, h->m, h->V, h->ldv, h->m, h->n, out, sign);
             else
-                colnorm_glds_kernel<T, COLNORM_CV><<<(int)(h->n / T::BN), NTHREADS, T::G_LDS_BYTES + 4 * T::BN * 8, h->stream>>>(
-                    W, h->m, h->V, h->ldv, h->m, h->n, out, sign);
+                ACC_LAUNCH_LDS((colnorm_glds_kernel<T, COLNORM_CV>), grid, NTHREADS, lds, h->stream, W, h->m, h->V, h->ldv, h->m, h->n, out, sign);
         } else if (interior) colnorm_launch_t<TileBig<true, false>>(h, W, out, sign, vw);
         else colnorm_launch_t<TileBig<true, true>>(h, W, out, sign, vw);
     } else {
